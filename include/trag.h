@@ -1,0 +1,172 @@
+/*
+ * trag.h -- C ABI of the MI355X (gfx950) dense-retrieval library.
+ *
+ * The reference (trueno-rag, Rust) has no FFI: the seam this library replaces
+ * is the method surface of the concrete `VectorStore` (src/index.rs:323-437)
+ * plus `FusionStrategy::fuse` (src/fusion.rs:42-63). Each entry point cites the
+ * reference item a Rust binding would forward to it. Paths are relative to the
+ * reference tree.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only. Unless a name ends in `_device`, every
+ *    pointer is host memory owned by the caller; the library owns all device
+ *    memory behind the opaque handle.
+ *  - Rows are addressed by a u32 row index assigned at insert (insertion
+ *    order). The binding keeps the ChunkId <-> row tables (ChunkId is a random
+ *    UUID, src/chunk.rs:14-16, never compared numerically).
+ *  - Scores are "higher is better" for every metric (Euclidean is negated,
+ *    src/index.rs:400). Results come best first; equal scores are ordered by
+ *    ascending row index; NaN scores come last.
+ *  - Return value 0 = OK; the message of the last failure on the calling
+ *    thread is available from trag_last_error().
+ *  - Thread contract mirrors &self / &mut self: searches on one handle may run
+ *    concurrently (they serialise on an internal lock); insert/overwrite/
+ *    remove/reserve need exclusive access.
+ */
+#ifndef TRAG_H
+#define TRAG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trag_store trag_store;
+
+typedef enum trag_status {
+    TRAG_OK = 0,
+    TRAG_DIM_MISMATCH = 1,   /* Error::DimensionMismatch{expected,actual}, src/index.rs:365-370,387-392 */
+    TRAG_INVALID_CONFIG = 2, /* Error::InvalidConfig, src/index.rs:360-363 */
+    TRAG_DEVICE_ERROR = 3,   /* HIP failure -> Error::VectorStore(String), src/error.rs:38-39 */
+    TRAG_OOM = 4,
+    TRAG_INVALID_ARG = 5,
+    TRAG_UNSUPPORTED = 6
+} trag_status;
+
+/* DistanceMetric, src/index.rs:310-319 */
+typedef enum trag_metric { TRAG_COSINE = 0, TRAG_EUCLIDEAN = 1, TRAG_DOT_PRODUCT = 2 } trag_metric;
+
+/* How the corpus scan is computed. Results are identical in every mode. */
+typedef enum trag_scan_mode {
+    TRAG_SCAN_AUTO = 0,
+    TRAG_SCAN_EXACT = 1,  /* every row scored with the reference's sequential f32 order */
+    TRAG_SCAN_STREAM = 2  /* reassociated streaming scan + exact re-score of candidates */
+} trag_scan_mode;
+
+/* VectorStoreConfig, src/index.rs:283-307 (the hnsw_* fields are never read by
+ * the reference and have no counterpart here). */
+typedef struct trag_config {
+    uint32_t dim;          /* VectorStoreConfig::dimension, default 384 */
+    uint32_t metric;       /* trag_metric, default cosine */
+    int32_t device;        /* HIP device ordinal; -1 = current device */
+    uint32_t scan_mode;    /* trag_scan_mode */
+    uint64_t reserve_rows; /* capacity hint, 0 = grow on demand */
+} trag_config;
+
+/* VectorStore::new / with_dimension, src/index.rs:335-350 */
+trag_status trag_store_create(const trag_config *cfg, trag_store **out);
+void trag_store_destroy(trag_store *s);
+
+/* VectorStore::config, src/index.rs:354-356 */
+trag_status trag_store_config(const trag_store *s, trag_config *out);
+
+/* VectorStore::insert / insert_batch, src/index.rs:359-383. Appends n rows of
+ * `dim` floats (row-major). dim != configured dimension -> TRAG_DIM_MISMATCH
+ * and nothing is inserted. rows == NULL with n > 0 -> TRAG_INVALID_CONFIG
+ * ("chunk must have embedding"). *out_first_row receives the index of the
+ * first appended row. A duplicate ChunkId is the binding's job: it calls
+ * trag_store_overwrite on the existing row (the reference overwrites,
+ * src/index.rs:372). */
+trag_status trag_store_insert(trag_store *s, const float *rows, uint64_t n, uint32_t dim,
+                              uint32_t *out_first_row);
+trag_status trag_store_overwrite(trag_store *s, uint32_t row, const float *vec, uint32_t dim);
+
+/* VectorStore::remove, src/index.rs:421-424. Tombstones the row: it is never
+ * returned again; its index is not reused. Removing a dead or out-of-range
+ * row is TRAG_INVALID_ARG (the binding maps that to None). */
+trag_status trag_store_remove(trag_store *s, uint32_t row);
+
+/* VectorStore::len / is_empty, src/index.rs:428-436: live rows. */
+uint64_t trag_store_len(const trag_store *s);
+/* Rows ever inserted (live + tombstoned) = next row index. */
+uint64_t trag_store_rows(const trag_store *s);
+trag_status trag_store_reserve(trag_store *s, uint64_t rows);
+
+/* VectorStore::search, src/index.rs:386-412. dim != configured dimension ->
+ * TRAG_DIM_MISMATCH. Writes *out_n = min(k, live rows) results; k == 0, an
+ * empty store and k > len are not errors (src/index.rs:409). out_rows and
+ * out_scores must hold k entries. */
+trag_status trag_store_search(trag_store *s, const float *query, uint32_t dim, uint32_t k,
+                              uint32_t *out_rows, float *out_scores, uint32_t *out_n);
+
+/* The same for B queries (row-major B x dim), the shape HybridRetriever /
+ * DenseRetriever callers produce when many queries are in flight
+ * (src/retrieve.rs:181,225,286). Outputs are B x k with out_n[b] valid entries
+ * in row b. */
+trag_status trag_store_search_batch(trag_store *s, const float *queries, uint32_t n_queries,
+                                    uint32_t dim, uint32_t k, uint32_t *out_rows,
+                                    float *out_scores, uint32_t *out_n);
+
+/* Device-resident variant: d_queries, d_out_* are device pointers on the
+ * store's device; work is enqueued on `hip_stream` (a hipStream_t, NULL = the
+ * default stream) and the call returns without waiting. d_status[b] (optional,
+ * may be NULL) receives 0 when query b's result is final; a non-zero value
+ * means the streaming scan could not certify the ranking and the caller must
+ * repeat that query (trag_store_search does this internally). With
+ * TRAG_SCAN_EXACT the status is always 0. */
+trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint32_t n_queries,
+                                     uint32_t dim, uint32_t k, uint32_t *d_out_rows,
+                                     float *d_out_scores, uint32_t *d_out_n,
+                                     uint32_t *d_status, void *hip_stream);
+
+/* Append n rows produced on the device by the library's counter-based
+ * synthetic generator (seeded, unit-norm rows); used by benchmarks so that a
+ * multi-GB corpus never crosses PCIe. No counterpart in the reference. */
+trag_status trag_store_fill_synthetic(trag_store *s, uint64_t n, uint64_t seed,
+                                      uint32_t *out_first_row);
+/* Copy rows [row0, row0+n) back to host memory (n x dim floats). */
+trag_status trag_store_read_rows(const trag_store *s, uint64_t row0, uint64_t n, float *out);
+
+/* FusionStrategy::fuse, src/fusion.rs:42-63. strategy: 0 RRF{k=param}
+ * (:68-84), 1 Linear{dense_weight=param} (:87-109), 2 Convex{alpha=param}
+ * (:112-119), 3 DBSF (:122-138), 4 Union (:141-160), 5 Intersection
+ * (:163-180). Ids are opaque u64 tokens (the binding passes row indices or its
+ * own id table positions). Writes *out_n <= nd + ns fused entries, best first
+ * (src/fusion.rs:227-231); equal fused scores keep first-appearance order
+ * (dense list, then sparse list). Pure host code: the inputs are <= 100
+ * entries (src/retrieve.rs:94,176). */
+trag_status trag_fuse(uint32_t strategy, float param, const uint64_t *dense_ids,
+                      const float *dense_scores, uint32_t nd, const uint64_t *sparse_ids,
+                      const float *sparse_scores, uint32_t ns, uint64_t *out_ids,
+                      float *out_scores, uint32_t *out_n);
+/* Shorthand for the default strategy, RRF (src/fusion.rs:33-37): scores of the
+ * inputs are ignored, only their order matters. */
+trag_status trag_fuse_rrf(const uint64_t *dense_ids, uint32_t nd, const uint64_t *sparse_ids,
+                          uint32_t ns, float k, uint64_t *out_ids, float *out_scores,
+                          uint32_t *out_n);
+
+/* Merge per-shard top-k lists (row-sharded corpus, one list per shard, global
+ * row ids) into the global top-k with the same ordering rule as search.
+ * lists are n_lists x k_in, list_n[i] valid entries each. Host code. */
+trag_status trag_merge_topk(const uint32_t *rows, const float *scores, const uint32_t *list_n,
+                            uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t *out_rows,
+                            float *out_scores, uint32_t *out_n);
+
+/* Counters of the last search on this handle (diagnostics). */
+typedef struct trag_search_stats {
+    uint32_t mode_used;      /* trag_scan_mode actually run */
+    uint32_t candidates;     /* rows that reached the final sort */
+    uint32_t refine_levels;  /* radix-select levels needed (1..3) */
+    uint32_t fallbacks;      /* queries repeated with the exact scan */
+} trag_search_stats;
+trag_status trag_store_last_stats(const trag_store *s, trag_search_stats *out);
+
+const char *trag_last_error(void);
+const char *trag_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRAG_H */

@@ -1,0 +1,362 @@
+"""GPU: the HIP path through the C ABI against the CPU oracle (bit-exact rows,
+ranks and score bits) and against the reference's VectorStore unit tests
+(src/index.rs:667-936)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from util import assert_same_ranking, unit_rows
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "ref_unit_vectors.json")))
+METRIC = {"cosine": 0, "euclidean": 1, "dot": 2}
+EXACT, STREAM = 1, 2
+
+
+def make_store(trag, dim, metric=0, mode=0, reserve=0):
+    return trag.VectorStore(trag.VectorStoreConfig(dimension=dim, metric=trag.DistanceMetric(metric),
+                                                   scan_mode=mode, reserve_rows=reserve))
+
+
+def chunk(trag, emb, text="x"):
+    return trag.Chunk(content=text, embedding=None if emb is None else list(emb))
+
+
+# ---------------- the reference's own unit tests ----------------
+
+def test_vector_store_new(trag):
+    store = trag.VectorStore.with_dimension(384)
+    assert store.config().dimension == 384 and store.is_empty()
+
+
+def test_vector_store_insert_get_remove(trag):
+    store = trag.VectorStore.with_dimension(3)
+    c = chunk(trag, [1.0, 0.0, 0.0])
+    store.insert(c)
+    assert store.len() == 1 and not store.is_empty() and store.get(c.id) is c
+    assert store.remove(c.id) is c
+    assert store.len() == 0 and store.get(c.id) is None
+    assert store.remove(trag.ChunkId()) is None                 # src/index.rs:815-819
+    assert store.search([1.0, 0.0, 0.0], 5) == []
+
+
+def test_insert_errors(trag):
+    store = trag.VectorStore.with_dimension(3)
+    with pytest.raises(trag.InvalidConfig):                      # src/index.rs:704-710
+        store.insert(chunk(trag, None))
+    with pytest.raises(trag.DimensionMismatch) as e:             # src/index.rs:713-726
+        store.insert(chunk(trag, [1.0, 0.0]))
+    assert (e.value.expected, e.value.actual) == (3, 2)
+    with pytest.raises(trag.DimensionMismatch) as e:             # src/index.rs:793-797
+        store.search([1.0, 0.0], 10)
+    assert (e.value.expected, e.value.actual) == (3, 2)
+    assert store.len() == 0
+
+
+def test_c_abi_error_codes(trag):
+    import ctypes as C
+    L = trag.lib()
+    store = trag.VectorStore.with_dimension(3)
+    v = np.zeros(2, dtype=np.float32)
+    fp = C.POINTER(C.c_float)
+    assert L.trag_store_insert(store.handle, v.ctypes.data_as(fp), 1, 2, None) == 1
+    assert b"expected 3" in L.trag_last_error()
+    assert L.trag_store_insert(store.handle, None, 1, 3, None) == 2
+    n = C.c_uint32(77)
+    assert L.trag_store_search(store.handle, v.ctypes.data_as(fp), 2, 5, None, None, C.byref(n)) == 1
+    assert L.trag_store_remove(store.handle, 0) == 5
+
+
+@pytest.mark.parametrize("case", GOLD["vector_store"], ids=lambda c: c["name"])
+def test_reference_search_cases(trag, oracle, case):
+    if case.get("rows_rule") == "one_hot_1000":
+        rows = np.zeros((1000, 128), dtype=np.float32)
+        rows[np.arange(1000), np.arange(1000) % 128] = 1.0
+        q = np.ones(128, dtype=np.float32)
+    else:
+        rows, q = np.array(case["rows"], dtype=np.float32), np.array(case["query"], dtype=np.float32)
+    for mode in (EXACT, STREAM):
+        store = make_store(trag, rows.shape[1], METRIC[case["metric"]], mode)
+        chunks = [chunk(trag, r, f"chunk {i}") for i, r in enumerate(rows)]
+        store.insert_batch(chunks)
+        res = store.search(q, case["k"])
+        assert len(res) == case["expect_len"]
+        order = [chunks.index(store.get(cid)) for cid, _ in res]
+        for key in ("expect_order_prefix", "expect_order_prefix_tie_rule"):
+            if key in case:
+                assert order[:len(case[key])] == case[key]
+        er, es = oracle.search(rows, q, case["k"], METRIC[case["metric"]])
+        assert_same_ranking(order, [s for _, s in res], er, es, case["name"])
+        if case.get("rows_rule"):                                 # the bench also asks for top-100
+            r100, s100 = store.search_rows(q, 100)
+            er, es = oracle.search(rows, q, 100, 0)
+            assert_same_ranking(r100, s100, er, es, "search_top_100")
+
+
+def test_prop_search_returns_stored(trag):
+    """prop_vector_store_search_returns_stored, src/index.rs:913-935"""
+    rng = np.random.default_rng(1)
+    for _ in range(8):
+        dim, n = int(rng.integers(2, 10)), int(rng.integers(1, 20))
+        store = trag.VectorStore.with_dimension(dim)
+        ids = []
+        for i in range(n):
+            e = [0.0] * dim
+            e[i % dim] = 1.0
+            c = chunk(trag, e, f"chunk {i}")
+            ids.append(c.id)
+            store.insert(c)
+        res = store.search([1.0] * dim, n)
+        assert len(res) == n and all(cid in ids for cid, _ in res)
+
+
+# ---------------- parity with the oracle on seeded inputs ----------------
+
+SHAPES = [(1, 3), (5, 2), (63, 8), (64, 100), (65, 128), (700, 36), (1000, 384), (3000, 768), (300, 4096),
+          (2500, 256), (999, 7)]
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d", SHAPES)
+def test_parity_small(trag, oracle, n, d, metric):
+    rng = np.random.default_rng(n * 131 + d)
+    corpus = unit_rows(rng, n, d) if metric == 0 else rng.standard_normal((n, d)).astype(np.float32)
+    queries = rng.standard_normal((3, d)).astype(np.float32)
+    for mode in (EXACT, STREAM):
+        store = make_store(trag, d, metric, mode)
+        store.insert_rows(corpus)
+        assert store.len() == n
+        for q in queries:
+            for k in (1, 10, 50, 100):
+                rows, scores = store.search_rows(q, k)
+                er, es = oracle.search(corpus, q, k, metric)
+                assert_same_ranking(rows, scores, er, es, f"n={n} d={d} metric={metric} mode={mode} k={k}")
+
+
+@pytest.mark.parametrize("mode", [EXACT, STREAM])
+def test_parity_100k_x_384(trag, oracle, mode):
+    n, d = 100_000, 384
+    store = make_store(trag, d, 0, mode, reserve=n)
+    store.fill_synthetic(n, 1002)
+    corpus = oracle.synth_rows(1002, 0, n, d)
+    got = store.read_rows(0, n)
+    assert got.tobytes() == corpus.tobytes(), "device generator and host generator differ"
+    queries = oracle.synth_rows(1102, 0, 8, d)
+    for q in queries:
+        for k in (10, 50, 100):
+            rows, scores = store.search_rows(q, k)
+            er, es = oracle.search(corpus, q, k, 0)
+            assert_same_ranking(rows, scores, er, es, f"100k mode={mode} k={k}")
+    st = store.last_stats()
+    assert st["fallbacks"] == 0
+    assert st["mode_used"] == mode
+
+
+def test_batch_matches_single(trag, oracle):
+    n, d, B, k = 20_000, 128, 17, 10
+    rng = np.random.default_rng(77)
+    corpus = unit_rows(rng, n, d)
+    Q = unit_rows(rng, B, d)
+    store = make_store(trag, d)
+    store.insert_rows(corpus)
+    rows, scores, cnt = store.search_batch_rows(Q, k)
+    assert cnt.tolist() == [k] * B
+    for b in range(B):
+        er, es = oracle.search(corpus, Q[b], k, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"batch query {b}")
+
+
+def test_device_pointer_entry(trag, oracle):
+    import ctypes as C
+    import torch
+    n, d, B, k = 30_000, 384, 4, 10
+    store = make_store(trag, d, 0, EXACT, reserve=n)
+    store.fill_synthetic(n, 5)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(6, 0, B, d)
+    dQ = torch.from_numpy(Q).cuda()
+    d_rows = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+    d_scores = torch.zeros((B, k), dtype=torch.float32, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    d_st = torch.ones(B, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream()
+    rc = trag.lib().trag_store_search_device(store.handle, dQ.data_ptr(), B, d, k, d_rows.data_ptr(),
+                                             d_scores.data_ptr(), d_n.data_ptr(), d_st.data_ptr(),
+                                             C.c_void_p(stream.cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert d_n.tolist() == [k] * B and d_st.tolist() == [0] * B
+    for b in range(B):
+        er, es = oracle.search(corpus, Q[b], k, 0)
+        assert_same_ranking(d_rows[b].cpu().numpy().astype(np.uint32), d_scores[b].cpu().numpy(), er, es,
+                            f"device entry query {b}")
+
+
+# ---------------- edge cases ----------------
+
+@pytest.mark.parametrize("mode", [EXACT, STREAM])
+def test_k_edges_and_empty(trag, oracle, mode):
+    d = 128
+    store = make_store(trag, d, 0, mode)
+    q = np.ones(d, dtype=np.float32)
+    assert store.search_rows(q, 10)[0].size == 0            # empty store (src/index.rs:409)
+    rng = np.random.default_rng(2)
+    corpus = unit_rows(rng, 37, d)
+    store.insert_rows(corpus)
+    assert store.search_rows(q, 0)[0].size == 0             # k == 0
+    rows, scores = store.search_rows(q, 1000)               # k > len: all rows, sorted
+    er, es = oracle.search(corpus, q, 1000, 0)
+    assert rows.size == 37
+    assert_same_ranking(rows, scores, er, es, "k>n")
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("mode", [EXACT, STREAM])
+def test_zero_nan_inf_and_duplicates(trag, oracle, mode, metric):
+    d = 128
+    rng = np.random.default_rng(3)
+    corpus = rng.standard_normal((500, d)).astype(np.float32)
+    corpus[7] = 0.0                       # zero-norm row -> cosine exactly 0.0 (src/index.rs:445-446)
+    corpus[11] = corpus[400]              # exact duplicates: tie broken by lower row
+    corpus[12] = corpus[400]
+    corpus[20, 5] = np.nan                # NaN row ranks last
+    corpus[30] *= 1e-20                   # tiny norm
+    corpus[31] *= 1e15                    # large norm
+    store = make_store(trag, d, metric, mode)
+    store.insert_rows(corpus)
+    for q in (corpus[400].copy(), np.zeros(d, dtype=np.float32), corpus[7] + 1.0):
+        for k in (3, 10, 500):
+            rows, scores = store.search_rows(q, k)
+            er, es = oracle.search(corpus, q, k, metric)
+            assert_same_ranking(rows, scores, er, es, f"edge metric={metric} mode={mode} k={k}")
+
+
+@pytest.mark.parametrize("mode", [EXACT, STREAM])
+def test_remove_and_overwrite(trag, oracle, mode):
+    d, n = 384, 2000
+    rng = np.random.default_rng(4)
+    corpus = unit_rows(rng, n, d)
+    store = make_store(trag, d, 0, mode)
+    store.insert_rows(corpus)
+    q = corpus[123].copy()
+    dead = np.zeros(n, dtype=np.uint8)
+    for r in (123, 0, 1999, 64, 65):
+        store.remove_row(r)
+        dead[r] = 1
+    assert store.len() == n - 5
+    newv = unit_rows(rng, 1, d)[0]
+    import ctypes as C
+    assert trag.lib().trag_store_overwrite(store.handle, 77, newv.ctypes.data_as(C.POINTER(C.c_float)), d) == 0
+    corpus[77] = newv
+    for k in (10, 100):
+        rows, scores = store.search_rows(q, k)
+        er, es = oracle.search(corpus, q, k, 0, dead=dead)
+        assert_same_ranking(rows, scores, er, es, f"remove mode={mode}")
+    assert 123 not in store.search_rows(q, n)[0]
+    # duplicate ChunkId overwrites (src/index.rs:372)
+    s2 = trag.VectorStore.with_dimension(3)
+    c = chunk(trag, [1.0, 0.0, 0.0])
+    s2.insert(c)
+    c2 = trag.Chunk(content="again", embedding=[0.0, 1.0, 0.0], id=c.id)
+    s2.insert(c2)
+    assert s2.len() == 1 and s2.search([0.0, 1.0, 0.0], 1)[0][1] == 1.0
+
+
+@pytest.mark.parametrize("mode", [EXACT, STREAM])
+def test_huge_tie_group_is_cut_by_row(trag, oracle, mode):
+    """More rows tie on the k-th score than the final sort can hold: the lowest
+    rows win (bench-shaped one-hot data, 20 000 rows)."""
+    d, n = 128, 20_000
+    rows = np.zeros((n, d), dtype=np.float32)
+    rows[np.arange(n), np.arange(n) % d] = 1.0
+    rows[15_000] *= 3.0          # same cosine, different dot
+    rows[17_000, :] = 1.0        # the single best row
+    store = make_store(trag, d, 0, mode)
+    store.insert_rows(rows)
+    q = np.ones(d, dtype=np.float32)
+    for k in (10, 100):
+        got_r, got_s = store.search_rows(q, k)
+        er, es = oracle.search(rows, q, k, 0)
+        assert_same_ranking(got_r, got_s, er, es, f"tie cut mode={mode}")
+    assert store.last_stats()["refine_levels"] == 3
+
+
+@pytest.mark.parametrize("mode", [EXACT, STREAM])
+def test_clustered_scores_need_refinement(trag, oracle, mode):
+    """Scores packed into a narrow band (one coarse bin holds far more than the
+    final sort's capacity) force the second radix level."""
+    d, n = 384, 60_000
+    rng = np.random.default_rng(8)
+    centre = unit_rows(rng, 1, d)[0]
+    corpus = centre[None, :] + 0.02 * rng.standard_normal((n, d)).astype(np.float32)
+    corpus = np.ascontiguousarray(corpus, dtype=np.float32)
+    store = make_store(trag, d, 0, mode)
+    store.insert_rows(corpus)
+    q = centre + 0.02 * rng.standard_normal(d).astype(np.float32)
+    for k in (10, 100):
+        rows, scores = store.search_rows(q, k)
+        er, es = oracle.search(corpus, q, k, 0)
+        assert_same_ranking(rows, scores, er, es, f"clustered mode={mode}")
+    assert store.last_stats()["refine_levels"] >= 2
+
+
+def test_growth_keeps_rows(trag, oracle):
+    d = 128
+    rng = np.random.default_rng(5)
+    store = make_store(trag, d)
+    parts = [unit_rows(rng, n, d) for n in (10, 1500, 3000, 1)]
+    for p in parts:
+        store.insert_rows(p)
+    corpus = np.concatenate(parts)
+    assert store.read_rows(0, corpus.shape[0]).tobytes() == corpus.tobytes()
+    q = corpus[2000]
+    rows, scores = store.search_rows(q, 10)
+    er, es = oracle.search(corpus, q, 10, 0)
+    assert_same_ranking(rows, scores, er, es, "growth")
+
+
+def test_hybrid_retriever_path(trag, oracle):
+    """src/retrieve.rs:175-220 with a stub embedder and a stub sparse index."""
+    d, n = 128, 300
+    rng = np.random.default_rng(6)
+    corpus = unit_rows(rng, n, d)
+
+    class Emb:
+        def embed_query(self, text):
+            if not text:
+                raise ValueError("empty query")
+            return corpus[int(text)]
+
+    class Sparse:
+        def __init__(self):
+            self.ids = []
+
+        def add(self, c):
+            self.ids.append(c.id)
+
+        def search(self, query, k):
+            base = int(query)
+            return [(self.ids[(base + 7 * i) % len(self.ids)], 10.0 - i) for i in range(min(k, 50))]
+
+    hr = trag.HybridRetriever.new(trag.VectorStore.with_dimension(d), Sparse(), Emb())
+    chunks = [chunk(trag, corpus[i], f"doc {i}") for i in range(n)]
+    hr.index_batch(chunks)
+    assert hr.len() == n
+    res = hr.retrieve("42", 10)
+    assert len(res) == 10 and res[0].chunk is chunks[42]          # best in both lists
+    assert all(r.fused_score is not None for r in res)
+    assert all(res[i].fused_score >= res[i + 1].fused_score for i in range(9))
+    # same fusion by hand from the oracle
+    er, es = oracle.search(corpus, corpus[42], 50, 0)
+    sparse_rows = [(42 + 7 * i) % n for i in range(50)]
+    ids, fs = oracle.rrf(er.astype(np.uint64), np.array(sparse_rows, dtype=np.uint64), 60.0)
+    assert [chunks.index(r.chunk) for r in res] == ids[:10].tolist()
+    assert np.array([r.fused_score for r in res], dtype=np.float32).tobytes() == fs[:10].tobytes()
+    dres = hr.retrieve_dense("42", 5)
+    assert [chunks.index(r.chunk) for r in dres] == er[:5].tolist()
+    dr = trag.DenseRetriever.new(hr.dense_store(), Emb())
+    assert [chunks.index(r.chunk) for r in dr.retrieve("42", 5)] == er[:5].tolist()

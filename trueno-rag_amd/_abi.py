@@ -1,0 +1,104 @@
+"""ctypes declarations for every symbol of include/trag.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libtrag.so")
+
+OK, DIM_MISMATCH, INVALID_CONFIG, DEVICE_ERROR, OOM, INVALID_ARG, UNSUPPORTED = range(7)
+
+
+class TragError(RuntimeError):
+    """Error::VectorStore(String) and everything without a dedicated variant."""
+
+    def __init__(self, status, message):
+        super().__init__(f"trag status {status}: {message}")
+        self.status = status
+
+
+class DimensionMismatch(TragError):
+    """Error::DimensionMismatch { expected, actual } (src/error.rs of the reference)."""
+
+    def __init__(self, expected, actual, message=""):
+        super().__init__(DIM_MISMATCH, message or f"dimension mismatch: expected {expected}, got {actual}")
+        self.expected = expected
+        self.actual = actual
+
+
+class InvalidConfig(TragError):
+    """Error::InvalidConfig(String)."""
+
+    def __init__(self, message):
+        super().__init__(INVALID_CONFIG, message)
+
+
+class Config(C.Structure):
+    _fields_ = [("dim", C.c_uint32), ("metric", C.c_uint32), ("device", C.c_int32),
+                ("scan_mode", C.c_uint32), ("reserve_rows", C.c_uint64)]
+
+
+class SearchStats(C.Structure):
+    _fields_ = [("mode_used", C.c_uint32), ("candidates", C.c_uint32),
+                ("refine_levels", C.c_uint32), ("fallbacks", C.c_uint32)]
+
+
+# name -> (restype, argtypes); the single source the symbol-export test iterates over.
+_fp, _u32p, _u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_H = C.c_void_p
+SIGNATURES = {
+    "trag_store_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "trag_store_destroy": (None, [_H]),
+    "trag_store_config": (C.c_int, [_H, C.POINTER(Config)]),
+    "trag_store_insert": (C.c_int, [_H, _fp, C.c_uint64, C.c_uint32, _u32p]),
+    "trag_store_overwrite": (C.c_int, [_H, C.c_uint32, _fp, C.c_uint32]),
+    "trag_store_remove": (C.c_int, [_H, C.c_uint32]),
+    "trag_store_len": (C.c_uint64, [_H]),
+    "trag_store_rows": (C.c_uint64, [_H]),
+    "trag_store_reserve": (C.c_int, [_H, C.c_uint64]),
+    "trag_store_search": (C.c_int, [_H, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "trag_store_search_batch": (C.c_int, [_H, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "trag_store_search_device": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trag_store_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint64, _u32p]),
+    "trag_store_read_rows": (C.c_int, [_H, C.c_uint64, C.c_uint64, _fp]),
+    "trag_fuse": (C.c_int, [C.c_uint32, C.c_float, _u64p, _fp, C.c_uint32, _u64p, _fp, C.c_uint32,
+                            _u64p, _fp, _u32p]),
+    "trag_fuse_rrf": (C.c_int, [_u64p, C.c_uint32, _u64p, C.c_uint32, C.c_float, _u64p, _fp, _u32p]),
+    "trag_merge_topk": (C.c_int, [_u32p, _fp, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "trag_store_last_stats": (C.c_int, [_H, C.POINTER(SearchStats)]),
+    "trag_last_error": (C.c_char_p, []),
+    "trag_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def lib_path():
+    return _LIB
+
+
+def lib():
+    """Load libtrag.so (built by `make -C trueno-rag_amd/csrc`). No fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError(f"{_LIB} is missing: build it with `make -C trueno-rag_amd/csrc` "
+                              "(there is no CPU implementation to fall back to)")
+        L = C.CDLL(_LIB)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status, dim_expected=None, dim_actual=None):
+    if status == OK:
+        return
+    msg = lib().trag_last_error().decode("utf-8", "replace")
+    if status == DIM_MISMATCH:
+        raise DimensionMismatch(dim_expected, dim_actual, msg)
+    if status == INVALID_CONFIG:
+        raise InvalidConfig(msg)
+    raise TragError(status, msg)

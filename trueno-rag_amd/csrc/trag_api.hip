@@ -1,0 +1,441 @@
+// Host side of the C ABI declared in include/trag.h: the device-resident
+// vector store (row-major N x d fp32 in HBM, tombstone bitmap, per-handle
+// search scratch) and the search pipeline
+//     prep -> scan -> select (radix levels + compaction) -> final sort.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "trag.h"
+#include "trag_internal.h"
+
+using namespace trag;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+trag_status fail(trag_status st, const std::string& msg) {
+    g_last_error = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            return fail(_e == hipErrorOutOfMemory ? TRAG_OOM : TRAG_DEVICE_ERROR,             \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+        }                                                                                     \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
+            switched = hipSetDevice(dev) == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct trag_store {
+    trag_config cfg{};
+    int device = 0;
+    float* d_rows = nullptr;       // cap_rows x dim
+    uint64_t cap_rows = 0;
+    uint64_t n_rows = 0;           // rows ever inserted
+    uint64_t n_live = 0;
+    uint32_t* d_dead = nullptr;    // bitmap, (cap_rows + 31) / 32 words
+    std::vector<uint32_t> h_dead;  // host mirror
+    float* d_vmax_sq = nullptr;    // 1 float
+    // search scratch (one query in flight per handle)
+    Scratch scratch{};
+    uint64_t keys_cap = 0;
+    // staging for the host-pointer entry points
+    float* d_q = nullptr;
+    uint64_t d_q_cap = 0;          // floats
+    uint32_t* d_out_rows = nullptr;
+    float* d_out_scores = nullptr;
+    uint32_t* d_out_n = nullptr;
+    uint32_t* d_out_status = nullptr;
+    uint64_t out_cap_q = 0, out_cap_k = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    trag_search_stats stats{};
+};
+
+namespace {
+
+trag_status grow_rows(trag_store* s, uint64_t want_rows) {
+    if (want_rows <= s->cap_rows) return TRAG_OK;
+    if (want_rows > 0xFFFFFFF0ull) return fail(TRAG_INVALID_ARG, "row count exceeds u32 row ids");
+    uint64_t cap = std::max<uint64_t>(want_rows, s->cap_rows + s->cap_rows / 2);
+    cap = std::max<uint64_t>(cap, 1024);
+    cap = (cap + 63) & ~63ull;
+    float* nrows = nullptr;
+    uint32_t* ndead = nullptr;
+    const size_t row_bytes = (size_t)cap * s->cfg.dim * sizeof(float);
+    const size_t dead_words = (size_t)(cap + 31) / 32;
+    HIP_TRY(hipMalloc(&nrows, row_bytes));
+    hipError_t e = hipMalloc(&ndead, dead_words * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(nrows);
+        return fail(TRAG_OOM, std::string("hipMalloc(dead bitmap): ") + hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemsetAsync(ndead, 0, dead_words * sizeof(uint32_t), s->stream));
+    if (s->n_rows) {
+        HIP_TRY(hipMemcpyAsync(nrows, s->d_rows, (size_t)s->n_rows * s->cfg.dim * sizeof(float),
+                               hipMemcpyDeviceToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(ndead, s->d_dead, ((size_t)(s->n_rows + 31) / 32) * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, s->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->d_rows) (void)hipFree(s->d_rows);
+    if (s->d_dead) (void)hipFree(s->d_dead);
+    s->d_rows = nrows;
+    s->d_dead = ndead;
+    s->cap_rows = cap;
+    s->h_dead.resize(dead_words, 0u);
+    return TRAG_OK;
+}
+
+trag_status ensure_scratch(trag_store* s) {
+    if (!s->scratch.ctl) {
+        HIP_TRY(hipMalloc(&s->scratch.ctl, sizeof(SearchCtl)));
+        HIP_TRY(hipMalloc(&s->scratch.hist, HIST_LEVELS * HIST_BINS * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s->scratch.cand, CAND_CAP * sizeof(uint32_t)));
+    }
+    if (s->keys_cap < s->cap_rows) {
+        if (s->scratch.keys) (void)hipFree(s->scratch.keys);
+        s->scratch.keys = nullptr;
+        s->keys_cap = 0;
+        HIP_TRY(hipMalloc(&s->scratch.keys, (size_t)s->cap_rows * sizeof(uint32_t)));
+        s->keys_cap = s->cap_rows;
+    }
+    return TRAG_OK;
+}
+
+trag_status ensure_staging(trag_store* s, uint64_t nq, uint64_t k) {
+    const uint64_t need_q = nq * s->cfg.dim;
+    if (need_q > s->d_q_cap) {
+        if (s->d_q) (void)hipFree(s->d_q);
+        s->d_q = nullptr;
+        s->d_q_cap = 0;
+        HIP_TRY(hipMalloc(&s->d_q, need_q * sizeof(float)));
+        s->d_q_cap = need_q;
+    }
+    if (nq > s->out_cap_q || k > s->out_cap_k) {
+        const uint64_t cq = std::max(nq, s->out_cap_q), ck = std::max<uint64_t>(std::max(k, s->out_cap_k), 1);
+        if (s->d_out_rows) (void)hipFree(s->d_out_rows);
+        if (s->d_out_scores) (void)hipFree(s->d_out_scores);
+        if (s->d_out_n) (void)hipFree(s->d_out_n);
+        if (s->d_out_status) (void)hipFree(s->d_out_status);
+        s->d_out_rows = nullptr; s->d_out_scores = nullptr; s->d_out_n = nullptr; s->d_out_status = nullptr;
+        s->out_cap_q = s->out_cap_k = 0;
+        HIP_TRY(hipMalloc(&s->d_out_rows, cq * ck * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s->d_out_scores, cq * ck * sizeof(float)));
+        HIP_TRY(hipMalloc(&s->d_out_n, cq * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s->d_out_status, cq * sizeof(uint32_t)));
+        s->out_cap_q = cq;
+        s->out_cap_k = ck;
+    }
+    return TRAG_OK;
+}
+
+uint32_t pick_mode(const trag_store* s, uint32_t requested) {
+    uint32_t mode = requested;
+    if (mode == TRAG_SCAN_AUTO) mode = stream_supports_dim(s->cfg.dim) ? TRAG_SCAN_STREAM : TRAG_SCAN_EXACT;
+    if (mode == TRAG_SCAN_STREAM && !stream_supports_dim(s->cfg.dim)) mode = TRAG_SCAN_EXACT;
+    return mode;
+}
+
+// Enqueue the pipeline for n_queries device-resident queries on `st`.
+// Caller holds s->mu, has set the device and made sure n_live > 0 and k > 0.
+trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_queries, uint32_t k,
+                           uint32_t mode, uint32_t* d_out_rows, float* d_out_scores,
+                           uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
+    trag_status ts = ensure_scratch(s);
+    if (ts != TRAG_OK) return ts;
+    const uint32_t live = (uint32_t)s->n_live;
+    const uint32_t k_eff = std::min<uint32_t>(k, live);
+    const bool rescore = mode == TRAG_SCAN_STREAM;
+    uint64_t need64 = rescore ? (uint64_t)k_eff + STREAM_SLACK : k_eff;
+    const uint32_t need = (uint32_t)std::min<uint64_t>(need64, live);
+    if (need > CAND_CAP)
+        return fail(TRAG_UNSUPPORTED, "k exceeds the single-workgroup final sort (k <= " +
+                                          std::to_string(CAND_CAP - STREAM_SLACK) +
+                                          " unless the store holds fewer rows)");
+    ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+    for (uint32_t b = 0; b < n_queries; ++b) {
+        const float* q = d_queries + (size_t)b * s->cfg.dim;
+        HIP_TRY(launch_prep(q, a, s->scratch, need, k_eff, s->d_vmax_sq, st));
+        if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, st));
+        else HIP_TRY(launch_scan_exact(q, a, s->scratch, st));
+        HIP_TRY(launch_select(a, s->scratch, st));
+        HIP_TRY(launch_final(q, a, s->scratch, rescore, live, d_out_rows + (size_t)b * k,
+                             d_out_scores + (size_t)b * k, d_out_n + b,
+                             d_status ? d_status + b : nullptr, st));
+    }
+    s->stats.mode_used = mode;
+    return TRAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* trag_last_error(void) { return g_last_error.c_str(); }
+const char* trag_version(void) { return "trag-hip 0.1 (gfx950)"; }
+
+trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
+    if (!cfg || !out) return fail(TRAG_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->dim == 0) return fail(TRAG_INVALID_CONFIG, "dimension must be positive");
+    if (cfg->metric > TRAG_DOT_PRODUCT) return fail(TRAG_INVALID_CONFIG, "unknown metric");
+    if (cfg->scan_mode > TRAG_SCAN_STREAM) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(TRAG_DEVICE_ERROR, "no HIP device available (this library has no CPU path)");
+    int dev = cfg->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= ndev) return fail(TRAG_INVALID_CONFIG, "device ordinal out of range");
+    DeviceGuard guard(dev);
+    trag_store* s = new trag_store();
+    s->cfg = *cfg;
+    s->cfg.device = dev;
+    s->device = dev;
+    e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
+    e = hipMalloc(&s->d_vmax_sq, sizeof(float));
+    if (e == hipSuccess) e = hipMemset(s->d_vmax_sq, 0, sizeof(float));
+    if (e != hipSuccess) { trag_store_destroy(s); return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
+    if (cfg->reserve_rows) {
+        trag_status ts = grow_rows(s, cfg->reserve_rows);
+        if (ts != TRAG_OK) { trag_store_destroy(s); return ts; }
+    }
+    *out = s;
+    return TRAG_OK;
+}
+
+void trag_store_destroy(trag_store* s) {
+    if (!s) return;
+    DeviceGuard guard(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    (void)hipDeviceSynchronize();
+    void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->scratch.ctl, s->scratch.hist,
+                    s->scratch.cand, s->scratch.keys, s->d_q, s->d_out_rows, s->d_out_scores,
+                    s->d_out_n, s->d_out_status};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+trag_status trag_store_config(const trag_store* s, trag_config* out) {
+    if (!s || !out) return fail(TRAG_INVALID_ARG, "null argument");
+    *out = s->cfg;
+    return TRAG_OK;
+}
+
+uint64_t trag_store_len(const trag_store* s) { return s ? s->n_live : 0; }
+uint64_t trag_store_rows(const trag_store* s) { return s ? s->n_rows : 0; }
+
+trag_status trag_store_reserve(trag_store* s, uint64_t rows) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    return grow_rows(s, rows);
+}
+
+trag_status trag_store_insert(trag_store* s, const float* rows, uint64_t n, uint32_t dim,
+                              uint32_t* out_first_row) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    if (n > 0 && !rows) return fail(TRAG_INVALID_CONFIG, "chunk must have embedding");
+    if (dim != s->cfg.dim)
+        return fail(TRAG_DIM_MISMATCH, "dimension mismatch: expected " + std::to_string(s->cfg.dim) +
+                                           ", got " + std::to_string(dim));
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (out_first_row) *out_first_row = (uint32_t)s->n_rows;
+    if (n == 0) return TRAG_OK;
+    trag_status ts = grow_rows(s, s->n_rows + n);
+    if (ts != TRAG_OK) return ts;
+    float* dst = s->d_rows + (size_t)s->n_rows * dim;
+    HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(launch_update_vmax(dst, n, dim, s->d_vmax_sq, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->n_rows += n;
+    s->n_live += n;
+    return TRAG_OK;
+}
+
+trag_status trag_store_overwrite(trag_store* s, uint32_t row, const float* vec, uint32_t dim) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    if (!vec) return fail(TRAG_INVALID_CONFIG, "chunk must have embedding");
+    if (dim != s->cfg.dim)
+        return fail(TRAG_DIM_MISMATCH, "dimension mismatch: expected " + std::to_string(s->cfg.dim) +
+                                           ", got " + std::to_string(dim));
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (row >= s->n_rows) return fail(TRAG_INVALID_ARG, "row out of range");
+    if ((s->h_dead[row >> 5] >> (row & 31)) & 1u) return fail(TRAG_INVALID_ARG, "row was removed");
+    DeviceGuard guard(s->device);
+    float* dst = s->d_rows + (size_t)row * dim;
+    HIP_TRY(hipMemcpyAsync(dst, vec, (size_t)dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(launch_update_vmax(dst, 1, dim, s->d_vmax_sq, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return TRAG_OK;
+}
+
+trag_status trag_store_remove(trag_store* s, uint32_t row) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (row >= s->n_rows) return fail(TRAG_INVALID_ARG, "row out of range");
+    uint32_t& w = s->h_dead[row >> 5];
+    if ((w >> (row & 31)) & 1u) return fail(TRAG_INVALID_ARG, "row already removed");
+    w |= 1u << (row & 31);
+    DeviceGuard guard(s->device);
+    HIP_TRY(hipMemcpyAsync(s->d_dead + (row >> 5), &w, sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->n_live -= 1;
+    return TRAG_OK;
+}
+
+trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed, uint32_t* out_first_row) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (out_first_row) *out_first_row = (uint32_t)s->n_rows;
+    if (n == 0) return TRAG_OK;
+    trag_status ts = grow_rows(s, s->n_rows + n);
+    if (ts != TRAG_OK) return ts;
+    float* d_norm = nullptr;
+    HIP_TRY(hipMalloc(&d_norm, (size_t)n * sizeof(float)));
+    float* dst = s->d_rows + (size_t)s->n_rows * s->cfg.dim;
+    hipError_t e = launch_fill_synthetic(dst, s->n_rows, n, s->cfg.dim, seed, d_norm, s->stream);
+    if (e == hipSuccess) e = launch_update_vmax(dst, n, s->cfg.dim, s->d_vmax_sq, s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
+    (void)hipFree(d_norm);
+    if (e != hipSuccess) return fail(TRAG_DEVICE_ERROR, std::string("fill_synthetic: ") + hipGetErrorString(e));
+    s->n_rows += n;
+    s->n_live += n;
+    return TRAG_OK;
+}
+
+trag_status trag_store_read_rows(const trag_store* s, uint64_t row0, uint64_t n, float* out) {
+    if (!s || (!out && n)) return fail(TRAG_INVALID_ARG, "null argument");
+    if (row0 + n > s->n_rows) return fail(TRAG_INVALID_ARG, "row range out of bounds");
+    if (n == 0) return TRAG_OK;
+    DeviceGuard guard(s->device);
+    HIP_TRY(hipMemcpy(out, s->d_rows + (size_t)row0 * s->cfg.dim, (size_t)n * s->cfg.dim * sizeof(float),
+                      hipMemcpyDeviceToHost));
+    return TRAG_OK;
+}
+
+trag_status trag_store_search_device(trag_store* s, const float* d_queries, uint32_t n_queries,
+                                     uint32_t dim, uint32_t k, uint32_t* d_out_rows,
+                                     float* d_out_scores, uint32_t* d_out_n, uint32_t* d_status,
+                                     void* hip_stream) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    if (dim != s->cfg.dim)
+        return fail(TRAG_DIM_MISMATCH, "dimension mismatch: expected " + std::to_string(s->cfg.dim) +
+                                           ", got " + std::to_string(dim));
+    if (n_queries == 0) return TRAG_OK;
+    if (!d_queries || !d_out_n || (k && (!d_out_rows || !d_out_scores)))
+        return fail(TRAG_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (k == 0 || s->n_live == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_n, 0, n_queries * sizeof(uint32_t), st));
+        if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, n_queries * sizeof(uint32_t), st));
+        return TRAG_OK;
+    }
+    return enqueue_search(s, d_queries, n_queries, k, pick_mode(s, s->cfg.scan_mode), d_out_rows,
+                          d_out_scores, d_out_n, d_status, st);
+}
+
+trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_t n_queries,
+                                    uint32_t dim, uint32_t k, uint32_t* out_rows, float* out_scores,
+                                    uint32_t* out_n) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    if (dim != s->cfg.dim)
+        return fail(TRAG_DIM_MISMATCH, "dimension mismatch: expected " + std::to_string(s->cfg.dim) +
+                                           ", got " + std::to_string(dim));
+    if (n_queries == 0) return TRAG_OK;
+    if (!queries || !out_n || (k && (!out_rows || !out_scores)))
+        return fail(TRAG_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (k == 0 || s->n_live == 0) {
+        for (uint32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
+        return TRAG_OK;
+    }
+    DeviceGuard guard(s->device);
+    trag_status ts = ensure_staging(s, n_queries, k);
+    if (ts != TRAG_OK) return ts;
+    hipStream_t st = s->stream;
+    HIP_TRY(hipMemcpyAsync(s->d_q, queries, (size_t)n_queries * dim * sizeof(float),
+                           hipMemcpyHostToDevice, st));
+    uint32_t mode = pick_mode(s, s->cfg.scan_mode);
+    ts = enqueue_search(s, s->d_q, n_queries, k, mode, s->d_out_rows, s->d_out_scores, s->d_out_n,
+                        s->d_out_status, st);
+    if (ts != TRAG_OK) return ts;
+    std::vector<uint32_t> status(n_queries);
+    HIP_TRY(hipMemcpyAsync(out_rows, s->d_out_rows, (size_t)n_queries * k * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_scores, s->d_out_scores, (size_t)n_queries * k * sizeof(float),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_n, s->d_out_n, (size_t)n_queries * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status.data(), s->d_out_status, (size_t)n_queries * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    s->stats.fallbacks = 0;
+    if (mode == TRAG_SCAN_STREAM) {
+        // Repeat, with the exact scan, every query whose ranking could not be certified.
+        for (uint32_t b = 0; b < n_queries; ++b) {
+            if (status[b] == ST_OK) continue;
+            s->stats.fallbacks += 1;
+            ts = enqueue_search(s, s->d_q + (size_t)b * dim, 1, k, TRAG_SCAN_EXACT,
+                                s->d_out_rows + (size_t)b * k, s->d_out_scores + (size_t)b * k,
+                                s->d_out_n + b, s->d_out_status + b, st);
+            if (ts != TRAG_OK) return ts;
+            HIP_TRY(hipMemcpyAsync(out_rows + (size_t)b * k, s->d_out_rows + (size_t)b * k,
+                                   k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_scores + (size_t)b * k, s->d_out_scores + (size_t)b * k,
+                                   k * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_n + b, s->d_out_n + b, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        s->stats.mode_used = TRAG_SCAN_STREAM;
+    }
+    SearchCtl ctl;
+    HIP_TRY(hipMemcpy(&ctl, s->scratch.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+    s->stats.candidates = ctl.expect;
+    s->stats.refine_levels = ctl.resolved ? ctl.resolved : 3;
+    return TRAG_OK;
+}
+
+trag_status trag_store_search(trag_store* s, const float* query, uint32_t dim, uint32_t k,
+                              uint32_t* out_rows, float* out_scores, uint32_t* out_n) {
+    return trag_store_search_batch(s, query, 1, dim, k, out_rows, out_scores, out_n);
+}
+
+trag_status trag_store_last_stats(const trag_store* s, trag_search_stats* out) {
+    if (!s || !out) return fail(TRAG_INVALID_ARG, "null argument");
+    *out = s->stats;
+    return TRAG_OK;
+}
+
+}  // extern "C"

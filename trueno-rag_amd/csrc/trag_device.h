@@ -1,0 +1,53 @@
+// Device-side helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace trag {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Ordered 32-bit key of a score: larger key = better rank.
+//   0            removed row (never a result)
+//   1            NaN score (ranks after every number)
+//   >= 0x007FFFFF  -inf .. +inf in numeric order; -0.0 and +0.0 share one key
+// (the reference compares scores with partial_cmp, src/index.rs:408, for which
+// the two zeros are Equal).
+__device__ __forceinline__ uint32_t score_key(float s) {
+    if (s != s) return 1u;
+    s = s + 0.0f;  // -0.0 -> +0.0
+    uint32_t b = __float_as_uint(s);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_score(uint32_t k) {
+    uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(b);  // key 1 -> 0xFFFFFFFE, a NaN
+}
+
+// 64-bit sort key: score key, then lower row first.
+__device__ __forceinline__ unsigned long long rank_key(uint32_t skey, uint32_t row) {
+    return ((unsigned long long)skey << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+}
+
+__device__ __forceinline__ bool row_is_dead(const uint32_t* __restrict__ dead, uint32_t row) {
+    return (dead[row >> 5] >> (row & 31)) & 1u;
+}
+
+// Same integer hash as the host generator used by the tests.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ float synth_component(unsigned long long seed, unsigned long long row,
+                                                 uint32_t col) {
+    unsigned long long h = splitmix64(seed ^ splitmix64(row * 0x100000001B3ull + col));
+    int s = (int)(h & 0xFFFF) + (int)((h >> 16) & 0xFFFF) + (int)((h >> 32) & 0xFFFF) +
+            (int)((h >> 48) & 0xFFFF) - 131070;
+    return (float)s * (1.0f / 37837.0f);
+}
+
+}  // namespace trag

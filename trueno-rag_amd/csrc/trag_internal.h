@@ -1,0 +1,74 @@
+// Internal declarations shared by the host API and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "trag.h"
+
+namespace trag {
+
+// Radix-select geometry: three levels over the 32-bit ordered key, 11 + 11 + 10 bits.
+constexpr uint32_t HIST_BINS = 2048;
+constexpr uint32_t HIST_LEVELS = 3;
+// Most rows that may reach the final single-workgroup sort.
+constexpr uint32_t CAND_CAP = 4096;
+// Extra candidates beyond k requested by the streaming mode, so that the
+// exactly re-scored top-k can be certified against everything left behind.
+constexpr uint32_t STREAM_SLACK = 32;
+
+// Final status written per query.
+constexpr uint32_t ST_OK = 0;
+constexpr uint32_t ST_UNCERTIFIED = 1;  // streaming scan: margin check failed, repeat exactly
+
+// Per-query control block in device memory. Written by prep_kernel and by
+// block 0 of each select stage; read by the stages after it on the same stream.
+struct SearchCtl {
+    float na;            // ||q|| with the reference's sequential f32 sum and sqrt
+    float na_sq;         // sum q*q, same order
+    float vmax_sq;       // upper bound of max_row sum v*v (streaming error bound)
+    uint32_t need;       // rows wanted at the final sort: min(k + slack, live)
+    uint32_t k;          // results wanted: min(k, live)
+    uint32_t resolved;   // 0 while the threshold is open, else the level that fixed it
+    uint32_t b1, above1; // level-1 bin holding the need-th key, rows strictly above it
+    uint32_t b2, above2; // level 2, cumulative
+    uint32_t t_key;      // accept keys >= t_key (or > t_key when cut_ties)
+    uint32_t cut_ties;   // 1: more than CAND_CAP rows tie on the need-th key
+    uint32_t tie_quota;  // ties to take, lowest rows first
+    uint32_t above3;     // rows strictly above t_key when cut_ties
+    uint32_t expect;     // candidates the final stage must find
+    uint32_t cand_count; // atomic append cursor
+    uint32_t status;
+    uint32_t pad;
+};
+
+// Device scratch of one in-flight query.
+struct Scratch {
+    SearchCtl* ctl;      // 1
+    uint32_t* hist;      // HIST_LEVELS * HIST_BINS
+    uint32_t* cand;      // CAND_CAP row indices
+    uint32_t* keys;      // capacity rows, ordered 32-bit keys (0 = removed row)
+};
+
+struct ScanArgs {
+    const float* corpus;
+    const uint32_t* dead;  // tombstone bitmap, 1 bit per row
+    uint32_t n_rows;
+    uint32_t dim;
+    uint32_t metric;
+};
+
+// ---- kernel launchers (trag_kernels.hip) ----
+hipError_t launch_prep(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                       uint32_t k, const float* d_vmax_sq, hipStream_t st);
+hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s, hipStream_t st);
+hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, hipStream_t st);
+bool stream_supports_dim(uint32_t dim);
+hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st);
+hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
+                        uint32_t live, uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
+                        uint32_t* d_status, hipStream_t st);
+hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint32_t dim,
+                                 uint64_t seed, float* d_norm_tmp, hipStream_t st);
+hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
+                              hipStream_t st);
+
+}  // namespace trag

@@ -1,0 +1,662 @@
+// gfx950 kernels of the dense-retrieval path: query preparation, the exact
+// corpus scan, the radix-select stages and the final sort.
+//
+// This file is compiled with -ffp-contract=off: every `a * b` followed by `+`
+// below is two roundings, exactly as the reference's scalar f32 loops
+// (src/index.rs:440-462 of the reference). Fused multiply-adds appear only
+// where written as __builtin_fmaf.
+#include "trag_device.h"
+#include "trag_internal.h"
+
+namespace trag {
+
+// ---------------------------------------------------------------------------
+// prep: zero the histograms, initialise the control block, compute ||q||.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+prep_kernel(const float* __restrict__ q, uint32_t d, SearchCtl* __restrict__ ctl,
+            uint32_t* __restrict__ hist, uint32_t need, uint32_t k,
+            const float* __restrict__ vmax_sq) {
+    __shared__ float qs[4096];
+    const int tid = threadIdx.x;
+    for (uint32_t i = tid; i < HIST_LEVELS * HIST_BINS; i += 256) hist[i] = 0u;
+    // sum q*q in the reference's order (src/index.rs:442): one thread, left to right.
+    float acc = 0.0f;
+    for (uint32_t base = 0; base < d; base += 4096) {
+        const uint32_t len = min(4096u, d - base);
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += 256) qs[i] = q[base + i];
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t i = 0; i < len; ++i) {
+                float p = qs[i] * qs[i];
+                acc = acc + p;
+            }
+        }
+    }
+    if (tid == 0) {
+        ctl->na_sq = acc;
+        ctl->na = sqrtf(acc);
+        ctl->vmax_sq = vmax_sq ? *vmax_sq : 0.0f;
+        ctl->need = need;
+        ctl->k = k;
+        ctl->resolved = 0;
+        ctl->b1 = ctl->above1 = ctl->b2 = ctl->above2 = 0;
+        ctl->t_key = 0;
+        ctl->cut_ties = 0;
+        ctl->tie_quota = 0;
+        ctl->above3 = 0;
+        ctl->expect = 0;
+        ctl->cand_count = 0;
+        ctl->status = ST_OK;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Score arithmetic, reference order. METRIC: 0 cosine, 1 euclidean, 2 dot.
+// acc0 is the dot (or squared distance) accumulator, acc1 the row's sum of squares.
+// ---------------------------------------------------------------------------
+template <int METRIC>
+__device__ __forceinline__ void accum(float qv, float x, float& acc0, float& acc1) {
+    if (METRIC == 1) {
+        float t = qv - x;      // (x - y)
+        float p = t * t;       // .powi(2)
+        acc0 = acc0 + p;
+    } else {
+        float p = qv * x;
+        acc0 = acc0 + p;
+        if (METRIC == 0) {
+            float p2 = x * x;
+            acc1 = acc1 + p2;
+        }
+    }
+}
+
+template <int METRIC>
+__device__ __forceinline__ float finish_score(float acc0, float acc1, float na) {
+    if (METRIC == 0) {
+        float nb = sqrtf(acc1);
+        if (na == 0.0f || nb == 0.0f) return 0.0f;   // src/index.rs:445-446
+        float den = na * nb;
+        return acc0 / den;                           // src/index.rs:448
+    } else if (METRIC == 1) {
+        return -sqrtf(acc0);                         // src/index.rs:400,452-458
+    } else {
+        return acc0;                                 // src/index.rs:460-462
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exact scan, d % 4 == 0.
+//
+// One lane owns one row, so its sums run left to right exactly as the
+// reference's. To keep HBM reads coalesced each wave stages a tile of 64 rows x
+// 32 columns through a private, padded LDS image: 16-byte loads walk along the
+// rows (8 lanes cover 128 contiguous bytes of one row), the image is written
+// row-major with a 36-float stride, and every lane then reads its own row with
+// conflict-free ds_read_b128. Tiles are private to a wave: no workgroup
+// barrier in the loop. The next chunk's global loads are in flight while the
+// current chunk is reduced. Each row's ordered key goes to keys[], and a
+// workgroup-local histogram of the keys' top 11 bits is merged into hist[].
+// ---------------------------------------------------------------------------
+constexpr int EX_CW = 32;            // chunk width in floats
+constexpr int EX_STRIDE = EX_CW + 4; // padded LDS row stride in floats
+
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
+                     const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
+                     const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
+                     uint32_t* __restrict__ hist) {
+    __shared__ __attribute__((aligned(16))) float tiles[4][64 * EX_STRIDE];
+    __shared__ uint32_t lhist[HIST_BINS];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
+    __syncthreads();
+
+    float* tile = tiles[wid];
+    const uint32_t n_tiles = (n_rows + 63u) >> 6;
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t d4 = d >> 2;
+    const uint32_t n_chunks = (d + EX_CW - 1) / EX_CW;
+    const float na = ctl->na;
+    const int lrow = lane >> 3;   // row of a load within its group of 8
+    const int lcol = lane & 7;    // float4 column within the chunk
+
+    uint32_t t = blockIdx.x * 4u + wid;
+    if (t < n_tiles) {
+        v4f pre[8];
+        // issue the loads of chunk c of tile tt
+        auto issue = [&](uint32_t tt, uint32_t c) {
+            const uint32_t col4 = min(c * 8u + (uint32_t)lcol, d4 - 1u);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t r = min(tt * 64u + (uint32_t)(i * 8 + lrow), n_rows - 1u);
+                const v4f* p = reinterpret_cast<const v4f*>(corpus + (size_t)r * d) + col4;
+                pre[i] = __builtin_nontemporal_load(p);
+            }
+        };
+        issue(t, 0);
+        while (t < n_tiles) {
+            float acc0 = 0.0f, acc1 = 0.0f;
+            for (uint32_t c = 0; c < n_chunks; ++c) {
+                // stage chunk c (the reads of the previous chunk are older DS ops of this wave)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    *reinterpret_cast<v4f*>(&tile[(i * 8 + lrow) * EX_STRIDE + lcol * 4]) = pre[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // prefetch the next chunk (of this tile or of the wave's next tile)
+                if (c + 1 < n_chunks) issue(t, c + 1);
+                else if (t + n_waves < n_tiles) issue(t + n_waves, 0);
+                const float* __restrict__ qc = q + c * EX_CW;
+                const float* myrow = tile + lane * EX_STRIDE;
+                const uint32_t len = min((uint32_t)EX_CW, d - c * EX_CW);
+                if (len == EX_CW) {
+#pragma unroll
+                    for (int j = 0; j < EX_CW / 4; ++j) {
+                        const v4f x = *reinterpret_cast<const v4f*>(myrow + j * 4);
+                        accum<METRIC>(qc[j * 4 + 0], x.x, acc0, acc1);
+                        accum<METRIC>(qc[j * 4 + 1], x.y, acc0, acc1);
+                        accum<METRIC>(qc[j * 4 + 2], x.z, acc0, acc1);
+                        accum<METRIC>(qc[j * 4 + 3], x.w, acc0, acc1);
+                    }
+                } else {
+                    for (uint32_t j = 0; j < len / 4; ++j) {
+                        const v4f x = *reinterpret_cast<const v4f*>(myrow + j * 4);
+                        accum<METRIC>(qc[j * 4 + 0], x.x, acc0, acc1);
+                        accum<METRIC>(qc[j * 4 + 1], x.y, acc0, acc1);
+                        accum<METRIC>(qc[j * 4 + 2], x.z, acc0, acc1);
+                        accum<METRIC>(qc[j * 4 + 3], x.w, acc0, acc1);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            const uint32_t row = t * 64u + lane;
+            if (row < n_rows) {
+                uint32_t key = 0u;
+                if (!row_is_dead(dead, row)) {
+                    key = score_key(finish_score<METRIC>(acc0, acc1, na));
+                    atomicAdd(&lhist[key >> 21], 1u);
+                }
+                keys[row] = key;
+            }
+            t += n_waves;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)HIST_BINS; i += 256) {
+        const uint32_t h = lhist[i];
+        if (h) atomicAdd(&hist[i], h);
+    }
+}
+
+// Exact scan for any d (rows need no alignment): one thread per row, strided
+// loads. Used for dimensions that are not a multiple of 4 (toy sizes).
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+scan_exact_any_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
+                      const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
+                      const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
+                      uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lhist[HIST_BINS];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
+    __syncthreads();
+    const float na = ctl->na;
+    for (uint32_t row = blockIdx.x * 256u + tid; row < n_rows; row += gridDim.x * 256u) {
+        uint32_t key = 0u;
+        if (!row_is_dead(dead, row)) {
+            const float* v = corpus + (size_t)row * d;
+            float acc0 = 0.0f, acc1 = 0.0f;
+            for (uint32_t j = 0; j < d; ++j) accum<METRIC>(q[j], v[j], acc0, acc1);
+            key = score_key(finish_score<METRIC>(acc0, acc1, na));
+            atomicAdd(&lhist[key >> 21], 1u);
+        }
+        keys[row] = key;
+    }
+    __syncthreads();
+    for (int i = tid; i < (int)HIST_BINS; i += 256) {
+        const uint32_t h = lhist[i];
+        if (h) atomicAdd(&hist[i], h);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Radix select over keys[]: find the threshold key such that at least `need`
+// and at most CAND_CAP rows lie at or above it.
+// ---------------------------------------------------------------------------
+
+// Called by all 256 threads of a workgroup. hist has HIST_BINS bins. Returns
+// the highest bin b whose suffix count (bins >= b) reaches `need`, and the
+// count strictly above it. sh: 8 words of LDS.
+__device__ void find_bin(const uint32_t* __restrict__ hist, uint32_t need, uint32_t& bin,
+                         uint32_t& above, uint32_t* sh) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int top = (int)HIST_BINS - 1 - 8 * t;  // thread t owns bins top, top-1, ..., top-7
+    uint32_t h[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { h[i] = hist[top - i]; sum += h[i]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) sh[w] = incl;
+    if (t == 0) { sh[4] = 0; sh[5] = 0; }
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < w; ++i) base += sh[i];
+    const uint32_t total = sh[0] + sh[1] + sh[2] + sh[3];
+    incl += base;
+    const uint32_t excl = incl - sum;
+    if (need > total) need = total;
+    if (need > 0 && excl < need && need <= incl) {
+        uint32_t cum = excl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (cum + h[i] >= need) { sh[4] = (uint32_t)(top - i); sh[5] = cum; break; }
+            cum += h[i];
+        }
+    }
+    __syncthreads();
+    bin = sh[4];
+    above = sh[5];
+    __syncthreads();
+}
+
+// Level 2 (bits 20..10) and level 3 (bits 9..0) histogram passes. Each starts
+// by resolving the previous level; when the rows at or above that level's bin
+// already fit CAND_CAP the threshold is fixed and the pass is skipped.
+template <int LEVEL>
+__global__ void __launch_bounds__(256)
+refine_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __restrict__ ctl,
+              uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lhist[HIST_BINS];
+    __shared__ uint32_t sh[8];
+    const int tid = threadIdx.x;
+    // Workgroup 0 of this very launch may set `resolved` while others start:
+    // take one reading per workgroup so that all its threads agree.
+    if (tid == 0) sh[6] = ctl->resolved;
+    __syncthreads();
+    if (sh[6]) return;
+    const uint32_t need = ctl->need;
+    uint32_t prefix, shift_match, shift_bin, mask_bin;
+    if (LEVEL == 2) {
+        uint32_t b1, above1;
+        find_bin(hist, need, b1, above1, sh);
+        const uint32_t inbin = hist[b1];
+        if (above1 + inbin <= CAND_CAP) {
+            if (blockIdx.x == 0 && tid == 0) {
+                ctl->t_key = b1 << 21;
+                ctl->expect = above1 + inbin;
+                ctl->resolved = 1;
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && tid == 0) { ctl->b1 = b1; ctl->above1 = above1; }
+        prefix = b1; shift_match = 21; shift_bin = 10; mask_bin = 2047u;
+    } else {
+        const uint32_t b1 = ctl->b1, above1 = ctl->above1;
+        uint32_t b2, a2;
+        find_bin(hist + HIST_BINS, need - above1, b2, a2, sh);
+        const uint32_t inbin = hist[HIST_BINS + b2];
+        const uint32_t above2 = above1 + a2;
+        if (above2 + inbin <= CAND_CAP) {
+            if (blockIdx.x == 0 && tid == 0) {
+                ctl->t_key = (b1 << 21) | (b2 << 10);
+                ctl->expect = above2 + inbin;
+                ctl->resolved = 2;
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && tid == 0) { ctl->b2 = b2; ctl->above2 = above2; }
+        prefix = (b1 << 11) | b2; shift_match = 10; shift_bin = 0; mask_bin = 1023u;
+    }
+    for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256u + tid; i < n_rows; i += gridDim.x * 256u) {
+        const uint32_t key = keys[i];
+        if (key != 0u && (key >> shift_match) == prefix)
+            atomicAdd(&lhist[(key >> shift_bin) & mask_bin], 1u);
+    }
+    __syncthreads();
+    uint32_t* out = hist + (LEVEL - 1) * HIST_BINS;
+    for (int i = tid; i < (int)HIST_BINS; i += 256) {
+        const uint32_t h = lhist[i];
+        if (h) atomicAdd(&out[i], h);
+    }
+}
+
+// Collect the candidate rows. Rows strictly above the threshold (or at/above
+// it when they all fit) are appended in arbitrary order; the final stage sorts
+// them, so the result does not depend on that order. When more than CAND_CAP
+// rows tie on the threshold key itself, workgroup 0 adds exactly tie_quota of
+// them in ascending row order.
+__global__ void __launch_bounds__(256)
+compact_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __restrict__ ctl,
+               const uint32_t* __restrict__ hist, uint32_t* __restrict__ cand) {
+    __shared__ uint32_t sh[8];
+    __shared__ uint32_t wcnt[4];
+    __shared__ uint32_t taken_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t t_key, cut = 0, quota = 0, above3 = 0;
+    if (ctl->resolved) {
+        t_key = ctl->t_key;
+    } else {
+        const uint32_t need = ctl->need;
+        const uint32_t b1 = ctl->b1, b2 = ctl->b2, above2 = ctl->above2;
+        uint32_t b3, a3;
+        find_bin(hist + 2 * HIST_BINS, need - above2, b3, a3, sh);
+        const uint32_t inbin = hist[2 * HIST_BINS + b3];
+        above3 = above2 + a3;
+        t_key = (b1 << 21) | (b2 << 10) | b3;
+        uint32_t expect = above3 + inbin;
+        if (expect > CAND_CAP) { cut = 1; quota = need - above3; expect = need; }
+        if (blockIdx.x == 0 && tid == 0) {
+            ctl->t_key = t_key;
+            ctl->cut_ties = cut;
+            ctl->tie_quota = quota;
+            ctl->above3 = above3;
+            ctl->expect = expect;
+        }
+    }
+    const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
+    for (uint32_t base = blockIdx.x * 256u + wid * 64u; base < n_rows; base += gridDim.x * 256u) {
+        const uint32_t i = base + lane;
+        const uint32_t key = i < n_rows ? keys[i] : 0u;
+        const bool acc = cut ? (key > t_key) : (key >= t_min);
+        const unsigned long long m = __ballot(acc);
+        if (m) {
+            uint32_t pos0 = 0;
+            if (lane == 0) pos0 = atomicAdd(&ctl->cand_count, (uint32_t)__popcll(m));
+            pos0 = __shfl(pos0, 0);
+            if (acc) {
+                const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < CAND_CAP) cand[pos] = i;
+            }
+        }
+    }
+    if (cut && blockIdx.x == 0) {
+        if (tid == 0) taken_sh = 0;
+        __syncthreads();
+        for (uint32_t base = 0; base < n_rows; base += 256u) {
+            const uint32_t taken = taken_sh;
+            if (taken >= quota) break;
+            const uint32_t i = base + tid;
+            const bool tie = i < n_rows && keys[i] == t_key;
+            const unsigned long long m = __ballot(tie);
+            if (lane == 0) wcnt[wid] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t off = taken;
+            for (int w = 0; w < wid; ++w) off += wcnt[w];
+            if (tie) {
+                const uint32_t pos = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < quota) cand[above3 + pos] = i;
+            }
+            __syncthreads();
+            if (tid == 0) taken_sh = taken + wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// final: (optionally) re-score every candidate with the reference arithmetic,
+// sort by (score key, row) in one workgroup, certify, write the top k.
+// ---------------------------------------------------------------------------
+template <int METRIC>
+__device__ float exact_score_row(const float* __restrict__ v, const float* __restrict__ q,
+                                 uint32_t d, float na) {
+    float acc0 = 0.0f, acc1 = 0.0f;
+    if ((d & 3u) == 0u) {
+        const v4f* v4 = reinterpret_cast<const v4f*>(v);
+        for (uint32_t j = 0; j < d / 4; ++j) {
+            const v4f x = v4[j];
+            accum<METRIC>(q[j * 4 + 0], x.x, acc0, acc1);
+            accum<METRIC>(q[j * 4 + 1], x.y, acc0, acc1);
+            accum<METRIC>(q[j * 4 + 2], x.z, acc0, acc1);
+            accum<METRIC>(q[j * 4 + 3], x.w, acc0, acc1);
+        }
+    } else {
+        for (uint32_t j = 0; j < d; ++j) accum<METRIC>(q[j], v[j], acc0, acc1);
+    }
+    return finish_score<METRIC>(acc0, acc1, na);
+}
+
+template <int METRIC, bool RESCORE>
+__global__ void __launch_bounds__(1024)
+final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows,
+             uint32_t d, uint32_t live, SearchCtl* __restrict__ ctl,
+             const uint32_t* __restrict__ keys, const uint32_t* __restrict__ cand,
+             uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
+             uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_status) {
+    __shared__ unsigned long long sk[CAND_CAP];
+    const int tid = threadIdx.x;
+    uint32_t C = ctl->expect;
+    if (C > CAND_CAP) C = CAND_CAP;
+    uint32_t P = 64;
+    while (P < C) P <<= 1;
+    const float na = ctl->na;
+    for (uint32_t i = tid; i < P; i += 1024u) {
+        unsigned long long v = 0ull;
+        if (i < C) {
+            const uint32_t row = cand[i];
+            uint32_t skey;
+            if (RESCORE)
+                skey = score_key(exact_score_row<METRIC>(corpus + (size_t)row * d, q, d, na));
+            else
+                skey = keys[row];
+            v = rank_key(skey, row);
+        }
+        sk[i] = v;
+    }
+    // bitonic sort, descending
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < P / 2; i += 1024u) {
+                const uint32_t pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = sk[pos], b = sk[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if (desc ? (a < b) : (a > b)) { sk[pos] = b; sk[pos + stride] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t k = ctl->k;
+    const uint32_t n_out = k < C ? k : C;
+    for (uint32_t i = tid; i < n_out; i += 1024u) {
+        const unsigned long long v = sk[i];
+        out_rows[i] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
+        float s = key_score((uint32_t)(v >> 32));
+        if (METRIC == 1 && s == 0.0f) s = -0.0f;  // -(sqrt(0)) in the reference
+        out_scores[i] = s;
+    }
+    if (tid == 0) {
+        *out_n = n_out;
+        uint32_t status = ST_OK;
+        if (RESCORE && C < live && n_out > 0) {
+            // Every row left behind has an approximate score <= t (the select
+            // threshold) and approximate and exact scores differ by at most eps,
+            // so the exact top-k is certified when its last member clears t + eps.
+            const float u = 5.9604645e-08f;  // 2^-24
+            float eps = (2.0f * (float)d + 64.0f) * u;
+            const float vmax = sqrtf(ctl->vmax_sq);
+            if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
+            if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
+            // the bound assumes ||q||^2 is a normal number well inside the f32 range
+            const float nsq = ctl->na_sq;
+            if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f))) status = ST_UNCERTIFIED;
+            const uint32_t t_key = ctl->t_key;
+            const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
+            const float ek = key_score((uint32_t)(sk[n_out - 1] >> 32));
+            if (!(ek > t + eps) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
+        }
+        ctl->status = status;
+        if (out_status) *out_status = status;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Synthetic corpus: counter-based components, then a sequential-sum L2
+// normalisation per row (two passes so that the stores are coalesced).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+synth_norm_kernel(unsigned long long seed, unsigned long long row0, unsigned long long n,
+                  uint32_t d, float* __restrict__ norms) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    float ss = 0.0f;
+    for (uint32_t c = 0; c < d; ++c) {
+        const float v = synth_component(seed, row0 + i, c);
+        const float p = v * v;
+        ss = ss + p;
+    }
+    norms[i] = sqrtf(ss);
+}
+
+__global__ void __launch_bounds__(256)
+synth_fill_kernel(unsigned long long seed, unsigned long long row0, unsigned long long n,
+                  uint32_t d, const float* __restrict__ norms, float* __restrict__ rows) {
+    const unsigned long long total = n * (unsigned long long)d;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; e < total;
+         e += (unsigned long long)gridDim.x * 256ull) {
+        const unsigned long long i = e / d;
+        const uint32_t c = (uint32_t)(e - i * d);
+        float v = synth_component(seed, row0 + i, c);
+        const float nrm = norms[i];
+        if (nrm > 0.0f) v = v / nrm;
+        rows[e] = v;
+    }
+}
+
+// Upper bound of max over rows of sum v*v (any summation order; inflated by
+// 1e-3). One wave per row, coalesced.
+__global__ void __launch_bounds__(256)
+vmax_kernel(const float* __restrict__ rows, unsigned long long n, uint32_t d,
+            float* __restrict__ vmax_sq) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long w0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) >> 6;
+    const unsigned long long nw = ((unsigned long long)gridDim.x * 256ull) >> 6;
+    float best = 0.0f;
+    for (unsigned long long r = w0; r < n; r += nw) {
+        const float* v = rows + r * d;
+        float s = 0.0f;
+        for (uint32_t c = lane; c < d; c += 64) s = __builtin_fmaf(v[c], v[c], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = s * 1.001f;
+        if (!(s < INFINITY)) continue;  // non-finite rows are always re-scored exactly
+        best = fmaxf(best, s);
+    }
+    if (lane == 0 && best > 0.0f)
+        atomicMax(reinterpret_cast<unsigned int*>(vmax_sq), __float_as_uint(best));
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+hipError_t launch_prep(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                       uint32_t k, const float* d_vmax_sq, hipStream_t st) {
+    hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(256), 0, st, d_q, a.dim, s.ctl, s.hist, need, k,
+                       d_vmax_sq);
+    return hipGetLastError();
+}
+
+template <int METRIC>
+static void scan_exact_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s,
+                                hipStream_t st) {
+    if ((a.dim & 3u) == 0u) {
+        const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
+        const uint32_t grid = grid_for(n_tiles, 4, 256 * 3);
+        hipLaunchKernelGGL(scan_exact_v4_kernel<METRIC>, dim3(grid), dim3(256), 0, st, a.corpus,
+                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.hist);
+    } else {
+        const uint32_t grid = grid_for(a.n_rows, 256, 256 * 8);
+        hipLaunchKernelGGL(scan_exact_any_kernel<METRIC>, dim3(grid), dim3(256), 0, st, a.corpus,
+                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.hist);
+    }
+}
+
+hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s,
+                             hipStream_t st) {
+    switch (a.metric) {
+    case TRAG_COSINE: scan_exact_dispatch<0>(d_q, a, s, st); break;
+    case TRAG_EUCLIDEAN: scan_exact_dispatch<1>(d_q, a, s, st); break;
+    default: scan_exact_dispatch<2>(d_q, a, s, st); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st) {
+    const uint32_t grid = grid_for(a.n_rows, 256 * 16, 1024);
+    hipLaunchKernelGGL(refine_kernel<2>, dim3(grid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
+                       s.hist);
+    hipLaunchKernelGGL(refine_kernel<3>, dim3(grid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
+                       s.hist);
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
+                       s.hist, s.cand);
+    return hipGetLastError();
+}
+
+template <int METRIC>
+static void final_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
+                           uint32_t live, uint32_t* d_out_rows, float* d_out_scores,
+                           uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
+    if (rescore)
+        hipLaunchKernelGGL((final_kernel<METRIC, true>), dim3(1), dim3(1024), 0, st, a.corpus, d_q,
+                           a.n_rows, a.dim, live, s.ctl, s.keys, s.cand, d_out_rows, d_out_scores,
+                           d_out_n, d_status);
+    else
+        hipLaunchKernelGGL((final_kernel<METRIC, false>), dim3(1), dim3(1024), 0, st, a.corpus, d_q,
+                           a.n_rows, a.dim, live, s.ctl, s.keys, s.cand, d_out_rows, d_out_scores,
+                           d_out_n, d_status);
+}
+
+hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
+                             uint32_t live, uint32_t* d_out_rows, float* d_out_scores,
+                             uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
+    switch (a.metric) {
+    case TRAG_COSINE:
+        final_dispatch<0>(d_q, a, s, rescore, live, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        break;
+    case TRAG_EUCLIDEAN:
+        final_dispatch<1>(d_q, a, s, rescore, live, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        break;
+    default:
+        final_dispatch<2>(d_q, a, s, rescore, live, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint32_t dim,
+                                 uint64_t seed, float* d_norm_tmp, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_norm_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, seed,
+                       row0, n, dim, d_norm_tmp);
+    const uint32_t grid = grid_for(n * dim, 256 * 8, 256 * 16);
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, st, seed, row0, n, dim,
+                       d_norm_tmp, d_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
+                              hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = grid_for(n, 4, 256 * 8);
+    hipLaunchKernelGGL(vmax_kernel, dim3(grid), dim3(256), 0, st, d_rows, n, dim, d_vmax_sq);
+    return hipGetLastError();
+}
+
+}  // namespace trag
