@@ -26,6 +26,16 @@ def chunk(trag, emb, text="x"):
     return trag.Chunk(content=text, embedding=None if emb is None else list(emb))
 
 
+def test_single_hip_runtime(trag):
+    """libtrag.so and torch must share one HIP runtime, or device pointers
+    cannot cross between them."""
+    import torch
+    from trueno_rag_amd import _abi
+    trag.lib()
+    assert torch.cuda.is_available()
+    assert len(_abi.hip_runtimes_loaded()) == 1, _abi.hip_runtimes_loaded()
+
+
 # ---------------- the reference's own unit tests ----------------
 
 def test_vector_store_new(trag):

@@ -81,6 +81,14 @@ def lib():
     """Load libtrag.so (built by `make -C trueno-rag_amd/csrc`). No fallback."""
     global _lib
     if _lib is None:
+        # One process must hold one HIP runtime. PyTorch wheels bundle their own
+        # libamdhip64 (same SONAME as /opt/rocm's): importing torch first makes
+        # the dynamic loader bind libtrag.so to that already-loaded copy, so
+        # torch device pointers and streams are valid inside this library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(_LIB):
             raise ImportError(f"{_LIB} is missing: build it with `make -C trueno-rag_amd/csrc` "
                               "(there is no CPU implementation to fall back to)")
@@ -91,6 +99,16 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def hip_runtimes_loaded():
+    """Paths of every libamdhip64 mapped into this process (must be exactly one)."""
+    seen = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                seen.add(line.split()[-1])
+    return sorted(seen)
 
 
 def check(status, dim_expected=None, dim_actual=None):
