@@ -123,9 +123,12 @@ trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint
 
 /* Append n rows produced on the device by the library's counter-based
  * synthetic generator (seeded, unit-norm rows); used by benchmarks so that a
- * multi-GB corpus never crosses PCIe. No counterpart in the reference. */
+ * multi-GB corpus never crosses PCIe. Row i of the call is row
+ * first_global_row + i of the generator's stream, so the shards of a
+ * row-partitioned corpus are slices of one global corpus. No counterpart in
+ * the reference. */
 trag_status trag_store_fill_synthetic(trag_store *s, uint64_t n, uint64_t seed,
-                                      uint32_t *out_first_row);
+                                      uint64_t first_global_row, uint32_t *out_first_row);
 /* Copy rows [row0, row0+n) back to host memory (n x dim floats). */
 trag_status trag_store_read_rows(const trag_store *s, uint64_t row0, uint64_t n, float *out);
 
@@ -153,6 +156,24 @@ trag_status trag_fuse_rrf(const uint64_t *dense_ids, uint32_t nd, const uint64_t
 trag_status trag_merge_topk(const uint32_t *rows, const float *scores, const uint32_t *list_n,
                             uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t *out_rows,
                             float *out_scores, uint32_t *out_n);
+
+/* Device-side variant of trag_merge_topk for lists that an all-gather left in
+ * device memory: d_rows / d_scores are n_lists x k_in, d_list_n (may be NULL =
+ * all full) n_lists counts; n_lists * k_in <= 4096. Enqueued on hip_stream. */
+trag_status trag_merge_topk_device(const uint32_t *d_rows, const float *d_scores,
+                                   const uint32_t *d_list_n, uint32_t n_lists, uint32_t k_in,
+                                   uint32_t k_out, uint32_t *d_out_rows, float *d_out_scores,
+                                   uint32_t *d_out_n, void *hip_stream);
+
+/* Change the scan mode of later searches (trag_scan_mode). */
+trag_status trag_store_set_scan_mode(trag_store *s, uint32_t scan_mode);
+
+/* Scan-kernel timing with HIP events on the stream the kernel runs on. While
+ * enabled, every scan launch is bracketed by an event pair (at most 4096 are
+ * kept). trag_store_scan_time waits for the recorded events, returns their
+ * summed duration and count, and clears them. */
+trag_status trag_store_set_profiling(trag_store *s, int enabled);
+trag_status trag_store_scan_time(trag_store *s, double *total_ms, uint32_t *launches);
 
 /* Counters of the last search on this handle (diagnostics). */
 typedef struct trag_search_stats {

@@ -56,6 +56,8 @@ def lib():
         L.oracle_synth_rows.restype = None
         L.oracle_synth_rows.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, fp]
         L.oracle_num_threads.restype = C.c_int
+        L.oracle_bench_faithful.restype = C.c_double
+        L.oracle_bench_faithful.argtypes = [fp, C.c_uint64, C.c_uint32, C.c_int, fp, C.c_uint32, C.c_uint32, u32p, fp]
         _lib = L
     return _lib
 
@@ -151,6 +153,19 @@ def synth_rows(seed, row0, n, d, normalize=True):
     out = np.empty((n, d), dtype=np.float32)
     lib().oracle_synth_rows(seed, row0, n, d, 1 if normalize else 0, _p(out, C.c_float))
     return out
+
+
+def bench_faithful(corpus, queries, k, metric=COSINE):
+    """Median seconds per query of the reference-shaped single-thread search, plus
+    the last query's (rows, scores)."""
+    corpus, queries = _f32(corpus), _f32(queries)
+    n, d = corpus.shape
+    rows = np.empty(max(k, 1), dtype=np.uint32)
+    scores = np.empty(max(k, 1), dtype=np.float32)
+    sec = lib().oracle_bench_faithful(_p(corpus, C.c_float), n, d, metric, _p(queries, C.c_float),
+                                      queries.shape[0], k, _p(rows, C.c_uint32), _p(scores, C.c_float))
+    m = min(k, n)
+    return float(sec), rows[:m].copy(), scores[:m].copy()
 
 
 def num_threads():

@@ -427,3 +427,53 @@ int oracle_num_threads(void) {
     return 1;
 #endif
 }
+
+/* ------------------------- timed CPU baseline ---------------------------- */
+#include <time.h>
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/*
+ * The reference's CPU path restated and timed on one thread: every row is
+ * copied into its own heap allocation (Vec<f32>), rows are visited in a
+ * scrambled order (stand-in for HashMap iteration, src/index.rs:394-397), and
+ * each query runs oracle_search_faithful (score all, stable sort all, truncate).
+ * Only the searches are timed (the store is built beforehand). Returns the
+ * median seconds per query; the last query's results go to out_rows/out_scores.
+ */
+double oracle_bench_faithful(const float *corpus, uint64_t n, uint32_t d, int metric,
+                             const float *queries, uint32_t nq, uint32_t k, uint32_t *out_rows,
+                             float *out_scores) {
+    float **rows = (float **)malloc(sizeof(float *) * (size_t)(n ? n : 1));
+    uint32_t *order = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n ? n : 1));
+    double *t = (double *)malloc(sizeof(double) * (nq ? nq : 1));
+    for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    for (uint64_t i = n; i > 1; --i) { /* Fisher-Yates with the integer hash */
+        uint64_t j = splitmix64(i * 0x9E3779B97F4A7C15ull) % i;
+        uint32_t tmp = order[i - 1]; order[i - 1] = order[j]; order[j] = tmp;
+    }
+    for (uint64_t i = 0; i < n; ++i) { /* allocate in visiting order, like inserts into a map */
+        uint32_t r = order[i];
+        rows[r] = (float *)malloc(sizeof(float) * d);
+        memcpy(rows[r], corpus + (size_t)r * d, sizeof(float) * d);
+    }
+    for (uint32_t qi = 0; qi < nq; ++qi) {
+        double t0 = now_s();
+        oracle_search_faithful((const float *const *)rows, order, n, d, metric,
+                               queries + (size_t)qi * d, k, out_rows, out_scores);
+        t[qi] = now_s() - t0;
+    }
+    for (uint32_t i = 1; i < nq; ++i) { /* sort times */
+        double x = t[i]; uint32_t j = i;
+        while (j > 0 && t[j - 1] > x) { t[j] = t[j - 1]; --j; }
+        t[j] = x;
+    }
+    double med = nq ? t[nq / 2] : 0.0;
+    for (uint64_t i = 0; i < n; ++i) free(rows[i]);
+    free(rows); free(order); free(t);
+    return med;
+}

@@ -73,6 +73,10 @@ struct trag_store {
     hipStream_t stream = nullptr;
     std::mutex mu;
     trag_search_stats stats{};
+    // optional scan timing
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // created once, reused
+    size_t ev_used = 0;
 };
 
 namespace {
@@ -180,8 +184,22 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     for (uint32_t b = 0; b < n_queries; ++b) {
         const float* q = d_queries + (size_t)b * s->cfg.dim;
         HIP_TRY(launch_prep(q, a, s->scratch, need, k_eff, s->d_vmax_sq, st));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (s->profiling && s->ev_used < 4096) {
+            if (s->ev_used == s->ev_pool.size()) {
+                hipEvent_t a0, a1;
+                HIP_TRY(hipEventCreate(&a0));
+                HIP_TRY(hipEventCreate(&a1));
+                s->ev_pool.emplace_back(a0, a1);
+            }
+            e0 = s->ev_pool[s->ev_used].first;
+            e1 = s->ev_pool[s->ev_used].second;
+            s->ev_used += 1;
+            HIP_TRY(hipEventRecord(e0, st));
+        }
         if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, st));
         else HIP_TRY(launch_scan_exact(q, a, s->scratch, st));
+        if (e1) HIP_TRY(hipEventRecord(e1, st));
         HIP_TRY(launch_select(a, s->scratch, st));
         HIP_TRY(launch_final(q, a, s->scratch, rescore, live, d_out_rows + (size_t)b * k,
                              d_out_scores + (size_t)b * k, d_out_n + b,
@@ -234,6 +252,7 @@ void trag_store_destroy(trag_store* s) {
     DeviceGuard guard(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipDeviceSynchronize();
+    for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->scratch.ctl, s->scratch.hist,
                     s->scratch.cand, s->scratch.keys, s->d_q, s->d_out_rows, s->d_out_scores,
                     s->d_out_n, s->d_out_status};
@@ -312,7 +331,8 @@ trag_status trag_store_remove(trag_store* s, uint32_t row) {
     return TRAG_OK;
 }
 
-trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed, uint32_t* out_first_row) {
+trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
+                                      uint64_t first_global_row, uint32_t* out_first_row) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
@@ -323,7 +343,7 @@ trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed, 
     float* d_norm = nullptr;
     HIP_TRY(hipMalloc(&d_norm, (size_t)n * sizeof(float)));
     float* dst = s->d_rows + (size_t)s->n_rows * s->cfg.dim;
-    hipError_t e = launch_fill_synthetic(dst, s->n_rows, n, s->cfg.dim, seed, d_norm, s->stream);
+    hipError_t e = launch_fill_synthetic(dst, first_global_row, n, s->cfg.dim, seed, d_norm, s->stream);
     if (e == hipSuccess) e = launch_update_vmax(dst, n, s->cfg.dim, s->d_vmax_sq, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     (void)hipFree(d_norm);
@@ -430,6 +450,52 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
 trag_status trag_store_search(trag_store* s, const float* query, uint32_t dim, uint32_t k,
                               uint32_t* out_rows, float* out_scores, uint32_t* out_n) {
     return trag_store_search_batch(s, query, 1, dim, k, out_rows, out_scores, out_n);
+}
+
+trag_status trag_store_set_scan_mode(trag_store* s, uint32_t scan_mode) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    if (scan_mode > TRAG_SCAN_STREAM) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->cfg.scan_mode = scan_mode;
+    return TRAG_OK;
+}
+
+trag_status trag_store_set_profiling(trag_store* s, int enabled) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->profiling = enabled != 0;
+    s->ev_used = 0;
+    return TRAG_OK;
+}
+
+trag_status trag_store_scan_time(trag_store* s, double* total_ms, uint32_t* launches) {
+    if (!s || !total_ms || !launches) return fail(TRAG_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    double sum = 0.0;
+    for (size_t i = 0; i < s->ev_used; ++i) {
+        HIP_TRY(hipEventSynchronize(s->ev_pool[i].second));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = (uint32_t)s->ev_used;
+    s->ev_used = 0;
+    return TRAG_OK;
+}
+
+trag_status trag_merge_topk_device(const uint32_t* d_rows, const float* d_scores,
+                                   const uint32_t* d_list_n, uint32_t n_lists, uint32_t k_in,
+                                   uint32_t k_out, uint32_t* d_out_rows, float* d_out_scores,
+                                   uint32_t* d_out_n, void* hip_stream) {
+    if (!d_rows || !d_scores || !d_out_rows || !d_out_scores || !d_out_n)
+        return fail(TRAG_INVALID_ARG, "null argument");
+    if ((uint64_t)n_lists * k_in > CAND_CAP)
+        return fail(TRAG_UNSUPPORTED, "n_lists * k_in exceeds " + std::to_string(CAND_CAP));
+    HIP_TRY(launch_merge_topk(d_rows, d_scores, d_list_n, n_lists, k_in, k_out, d_out_rows,
+                              d_out_scores, d_out_n, (hipStream_t)hip_stream));
+    return TRAG_OK;
 }
 
 trag_status trag_store_last_stats(const trag_store* s, trag_search_stats* out) {

@@ -68,6 +68,9 @@ hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, b
                         uint32_t* d_status, hipStream_t st);
 hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint32_t dim,
                                  uint64_t seed, float* d_norm_tmp, hipStream_t st);
+hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_list_n,
+                             uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t* d_out_rows,
+                             float* d_out_scores, uint32_t* d_out_n, hipStream_t st);
 hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
                               hipStream_t st);
 

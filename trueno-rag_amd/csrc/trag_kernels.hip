@@ -500,6 +500,57 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
     }
 }
 
+// Merge of per-shard top-k lists (global row ids) that an all-gather left in
+// device memory: one workgroup sorts all entries by (score key, row).
+__global__ void __launch_bounds__(1024)
+merge_topk_kernel(const uint32_t* __restrict__ rows, const float* __restrict__ scores,
+                  const uint32_t* __restrict__ list_n, uint32_t n_lists, uint32_t k_in,
+                  uint32_t k_out, uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
+                  uint32_t* __restrict__ out_n) {
+    __shared__ unsigned long long sk[CAND_CAP];
+    __shared__ uint32_t total_sh;
+    const int tid = threadIdx.x;
+    const uint32_t C = n_lists * k_in;
+    uint32_t P = 64;
+    while (P < C) P <<= 1;
+    if (tid == 0) total_sh = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < P; i += 1024u) {
+        unsigned long long v = 0ull;
+        if (i < C) {
+            const uint32_t l = i / k_in, j = i - l * k_in;
+            const uint32_t n = list_n ? min(list_n[l], k_in) : k_in;
+            if (j < n) {
+                v = rank_key(score_key(scores[i]), rows[i]);
+                mine += 1;
+            }
+        }
+        sk[i] = v;
+    }
+    if (mine) atomicAdd(&total_sh, mine);
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < P / 2; i += 1024u) {
+                const uint32_t pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = sk[pos], b = sk[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if (desc ? (a < b) : (a > b)) { sk[pos] = b; sk[pos + stride] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = total_sh;
+    const uint32_t n_out = k_out < total ? k_out : total;
+    for (uint32_t i = tid; i < n_out; i += 1024u) {
+        const unsigned long long v = sk[i];
+        out_rows[i] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
+        out_scores[i] = key_score((uint32_t)(v >> 32));
+    }
+    if (tid == 0) *out_n = n_out;
+}
+
 // ---------------------------------------------------------------------------
 // Synthetic corpus: counter-based components, then a sequential-sum L2
 // normalisation per row (two passes so that the stores are coalesced).
@@ -648,6 +699,14 @@ hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint3
     const uint32_t grid = grid_for(n * dim, 256 * 8, 256 * 16);
     hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, st, seed, row0, n, dim,
                        d_norm_tmp, d_rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_list_n,
+                             uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t* d_out_rows,
+                             float* d_out_scores, uint32_t* d_out_n, hipStream_t st) {
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(1), dim3(1024), 0, st, d_rows, d_scores, d_list_n,
+                       n_lists, k_in, k_out, d_out_rows, d_out_scores, d_out_n);
     return hipGetLastError();
 }
 

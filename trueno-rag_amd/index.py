@@ -157,10 +157,36 @@ class VectorStore:
                                                 C.byref(first)), self._config.dimension, rows.shape[1])
         return first.value
 
-    def fill_synthetic(self, n: int, seed: int) -> int:
+    def fill_synthetic(self, n: int, seed: int, first_global_row: Optional[int] = None) -> int:
+        """Append n generator rows; generator row index starts at first_global_row
+        (default: the store's current row count)."""
         first = C.c_uint32()
-        _abi.check(_abi.lib().trag_store_fill_synthetic(self._h, n, seed, C.byref(first)))
+        g0 = self.rows() if first_global_row is None else first_global_row
+        _abi.check(_abi.lib().trag_store_fill_synthetic(self._h, n, seed, g0, C.byref(first)))
         return first.value
+
+    def rows(self) -> int:
+        return int(_abi.lib().trag_store_rows(self._h))
+
+    def set_scan_mode(self, mode: int) -> None:
+        _abi.check(_abi.lib().trag_store_set_scan_mode(self._h, mode))
+
+    def set_profiling(self, enabled: bool) -> None:
+        _abi.check(_abi.lib().trag_store_set_profiling(self._h, 1 if enabled else 0))
+
+    def scan_time(self):
+        """(total milliseconds, launches) of the scan kernels since profiling was enabled."""
+        ms, n = C.c_double(), C.c_uint32()
+        _abi.check(_abi.lib().trag_store_scan_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def search_device(self, d_queries_ptr: int, n_queries: int, k: int, d_rows_ptr: int, d_scores_ptr: int,
+                      d_n_ptr: int, d_status_ptr: int = 0, stream: int = 0) -> None:
+        """Asynchronous search on device-resident queries (raw device addresses)."""
+        _abi.check(_abi.lib().trag_store_search_device(
+            self._h, C.c_void_p(d_queries_ptr), n_queries, self._config.dimension, k, C.c_void_p(d_rows_ptr),
+            C.c_void_p(d_scores_ptr), C.c_void_p(d_n_ptr), C.c_void_p(d_status_ptr) if d_status_ptr else None,
+            C.c_void_p(stream) if stream else None), self._config.dimension, self._config.dimension)
 
     def read_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self._config.dimension), dtype=np.float32)
