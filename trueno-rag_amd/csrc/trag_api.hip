@@ -122,9 +122,12 @@ trag_status ensure_scratch(trag_store* s) {
     }
     if (s->keys_cap < s->cap_rows) {
         if (s->scratch.keys) (void)hipFree(s->scratch.keys);
+        if (s->scratch.tmax) (void)hipFree(s->scratch.tmax);
         s->scratch.keys = nullptr;
+        s->scratch.tmax = nullptr;
         s->keys_cap = 0;
         HIP_TRY(hipMalloc(&s->scratch.keys, (size_t)s->cap_rows * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&s->scratch.tmax, ((size_t)s->cap_rows / 64 + 1) * sizeof(uint32_t)));
         s->keys_cap = s->cap_rows;
     }
     return TRAG_OK;
@@ -159,7 +162,9 @@ trag_status ensure_staging(trag_store* s, uint64_t nq, uint64_t k) {
 
 uint32_t pick_mode(const trag_store* s, uint32_t requested) {
     uint32_t mode = requested;
-    if (mode == TRAG_SCAN_AUTO) mode = stream_supports_dim(s->cfg.dim) ? TRAG_SCAN_STREAM : TRAG_SCAN_EXACT;
+    // The exact-order scan measured faster than the streaming one on MI355X (it
+    // needs no re-score), so it is the default for every dimension.
+    if (mode == TRAG_SCAN_AUTO) mode = TRAG_SCAN_EXACT;
     if (mode == TRAG_SCAN_STREAM && !stream_supports_dim(s->cfg.dim)) mode = TRAG_SCAN_EXACT;
     return mode;
 }
@@ -254,7 +259,7 @@ void trag_store_destroy(trag_store* s) {
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->scratch.ctl, s->scratch.hist,
-                    s->scratch.cand, s->scratch.keys, s->d_q, s->d_out_rows, s->d_out_scores,
+                    s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->d_q, s->d_out_rows, s->d_out_scores,
                     s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

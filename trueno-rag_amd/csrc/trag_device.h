@@ -34,6 +34,16 @@ __device__ __forceinline__ bool row_is_dead(const uint32_t* __restrict__ dead, u
     return (dead[row >> 5] >> (row & 31)) & 1u;
 }
 
+// Largest value over the 64 lanes of a wave (every lane must call it).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t w = (uint32_t)__shfl_xor((int)v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
 // Same integer hash as the host generator used by the tests.
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;

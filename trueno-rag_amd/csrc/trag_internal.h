@@ -46,6 +46,7 @@ struct Scratch {
     uint32_t* hist;      // HIST_LEVELS * HIST_BINS
     uint32_t* cand;      // CAND_CAP row indices
     uint32_t* keys;      // capacity rows, ordered 32-bit keys (0 = removed row)
+    uint32_t* tmax;      // capacity rows / 64: largest key of each 64-row tile
 };
 
 struct ScanArgs {

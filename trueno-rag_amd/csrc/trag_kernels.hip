@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(256)
 prep_kernel(const float* __restrict__ q, uint32_t d, SearchCtl* __restrict__ ctl,
             uint32_t* __restrict__ hist, uint32_t need, uint32_t k,
             const float* __restrict__ vmax_sq) {
-    __shared__ float qs[4096];
+    __shared__ __attribute__((aligned(16))) float qs[4096];
     const int tid = threadIdx.x;
     for (uint32_t i = tid; i < HIST_LEVELS * HIST_BINS; i += 256) hist[i] = 0u;
     // sum q*q in the reference's order (src/index.rs:442): one thread, left to right.
@@ -28,7 +28,16 @@ prep_kernel(const float* __restrict__ q, uint32_t d, SearchCtl* __restrict__ ctl
         for (uint32_t i = tid; i < len; i += 256) qs[i] = q[base + i];
         __syncthreads();
         if (tid == 0) {
-            for (uint32_t i = 0; i < len; ++i) {
+            uint32_t i = 0;
+            for (; i + 4 <= len; i += 4) {  // wide LDS reads; the adds stay strictly in order
+                const v4f x = *reinterpret_cast<const v4f*>(&qs[i]);
+                float p0 = x.x * x.x, p1 = x.y * x.y, p2 = x.z * x.z, p3 = x.w * x.w;
+                acc = acc + p0;
+                acc = acc + p1;
+                acc = acc + p2;
+                acc = acc + p3;
+            }
+            for (; i < len; ++i) {
                 float p = qs[i] * qs[i];
                 acc = acc + p;
             }
@@ -107,7 +116,7 @@ __global__ void __launch_bounds__(256)
 scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
                      const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
                      const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
-                     uint32_t* __restrict__ hist) {
+                     uint32_t* __restrict__ tmax, uint32_t* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) float tiles[4][64 * EX_STRIDE];
     __shared__ uint32_t lhist[HIST_BINS];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -174,14 +183,16 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
                 __builtin_amdgcn_wave_barrier();
             }
             const uint32_t row = t * 64u + lane;
+            uint32_t key = 0u;
             if (row < n_rows) {
-                uint32_t key = 0u;
                 if (!row_is_dead(dead, row)) {
                     key = score_key(finish_score<METRIC>(acc0, acc1, na));
                     atomicAdd(&lhist[key >> 21], 1u);
                 }
                 keys[row] = key;
             }
+            const uint32_t tm = wave_max_u32(key);
+            if (lane == 0) tmax[t] = tm;
             t += n_waves;
         }
     }
@@ -199,22 +210,27 @@ __global__ void __launch_bounds__(256)
 scan_exact_any_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
                       const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
                       const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
-                      uint32_t* __restrict__ hist) {
+                      uint32_t* __restrict__ tmax, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lhist[HIST_BINS];
     const int tid = threadIdx.x;
     for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
     __syncthreads();
     const float na = ctl->na;
-    for (uint32_t row = blockIdx.x * 256u + tid; row < n_rows; row += gridDim.x * 256u) {
+    // each wave covers one aligned 64-row tile per iteration
+    for (uint32_t base = blockIdx.x * 256u; base < n_rows; base += gridDim.x * 256u) {
+        const uint32_t row = base + tid;
         uint32_t key = 0u;
-        if (!row_is_dead(dead, row)) {
+        if (row < n_rows && !row_is_dead(dead, row)) {
             const float* v = corpus + (size_t)row * d;
             float acc0 = 0.0f, acc1 = 0.0f;
             for (uint32_t j = 0; j < d; ++j) accum<METRIC>(q[j], v[j], acc0, acc1);
             key = score_key(finish_score<METRIC>(acc0, acc1, na));
             atomicAdd(&lhist[key >> 21], 1u);
         }
-        keys[row] = key;
+        if (row < n_rows) keys[row] = key;
+        const uint32_t tm = wave_max_u32(key);
+        const uint32_t tile = (base + (tid & ~63u)) >> 6;
+        if ((tid & 63) == 0 && (base + (tid & ~63u)) < n_rows) tmax[tile] = tm;
     }
     __syncthreads();
     for (int i = tid; i < (int)HIST_BINS; i += 256) {
@@ -336,8 +352,9 @@ refine_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __r
 // rows tie on the threshold key itself, workgroup 0 adds exactly tie_quota of
 // them in ascending row order.
 __global__ void __launch_bounds__(256)
-compact_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __restrict__ ctl,
-               const uint32_t* __restrict__ hist, uint32_t* __restrict__ cand) {
+compact_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax, uint32_t n_rows,
+               SearchCtl* __restrict__ ctl, const uint32_t* __restrict__ hist,
+               uint32_t* __restrict__ cand) {
     __shared__ uint32_t sh[8];
     __shared__ uint32_t wcnt[4];
     __shared__ uint32_t taken_sh;
@@ -364,18 +381,28 @@ compact_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __
         }
     }
     const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
-    for (uint32_t base = blockIdx.x * 256u + wid * 64u; base < n_rows; base += gridDim.x * 256u) {
-        const uint32_t i = base + lane;
-        const uint32_t key = i < n_rows ? keys[i] : 0u;
-        const bool acc = cut ? (key > t_key) : (key >= t_min);
-        const unsigned long long m = __ballot(acc);
-        if (m) {
-            uint32_t pos0 = 0;
-            if (lane == 0) pos0 = atomicAdd(&ctl->cand_count, (uint32_t)__popcll(m));
-            pos0 = __shfl(pos0, 0);
-            if (acc) {
-                const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < CAND_CAP) cand[pos] = i;
+    // Only tiles whose largest key reaches the threshold can hold a candidate:
+    // each lane tests one tile maximum, then the wave visits the tiles that pass.
+    const uint32_t n_tiles = (n_rows + 63u) >> 6;
+    for (uint32_t tbase = (blockIdx.x * 4u + wid) * 64u; tbase < n_tiles; tbase += gridDim.x * 256u) {
+        const uint32_t tile = tbase + lane;
+        const uint32_t tm = tile < n_tiles ? tmax[tile] : 0u;
+        unsigned long long hits = __ballot(cut ? (tm > t_key) : (tm >= t_min));
+        while (hits) {
+            const uint32_t j = (uint32_t)__ffsll((long long)hits) - 1u;
+            hits &= hits - 1ull;
+            const uint32_t i = (tbase + j) * 64u + lane;
+            const uint32_t key = i < n_rows ? keys[i] : 0u;
+            const bool acc = cut ? (key > t_key) : (key >= t_min);
+            const unsigned long long m = __ballot(acc);
+            if (m) {
+                uint32_t pos0 = 0;
+                if (lane == 0) pos0 = atomicAdd(&ctl->cand_count, (uint32_t)__popcll(m));
+                pos0 = __shfl(pos0, 0);
+                if (acc) {
+                    const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < CAND_CAP) cand[pos] = i;
+                }
             }
         }
     }
@@ -631,11 +658,11 @@ static void scan_exact_dispatch(const float* d_q, const ScanArgs& a, const Scrat
         const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
         const uint32_t grid = grid_for(n_tiles, 4, 256 * 3);
         hipLaunchKernelGGL(scan_exact_v4_kernel<METRIC>, dim3(grid), dim3(256), 0, st, a.corpus,
-                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.hist);
+                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.tmax, s.hist);
     } else {
         const uint32_t grid = grid_for(a.n_rows, 256, 256 * 8);
         hipLaunchKernelGGL(scan_exact_any_kernel<METRIC>, dim3(grid), dim3(256), 0, st, a.corpus,
-                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.hist);
+                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.tmax, s.hist);
     }
 }
 
@@ -650,13 +677,18 @@ hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch&
 }
 
 hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st) {
-    const uint32_t grid = grid_for(a.n_rows, 256 * 16, 1024);
-    hipLaunchKernelGGL(refine_kernel<2>, dim3(grid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
+    // The refinement passes are needed only when one coarse bin holds more rows
+    // than the final sort can take; otherwise they return at once, so keep
+    // their grids small.
+    const uint32_t rgrid = grid_for(a.n_rows, 256 * 16, 256);
+    hipLaunchKernelGGL(refine_kernel<2>, dim3(rgrid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
                        s.hist);
-    hipLaunchKernelGGL(refine_kernel<3>, dim3(grid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
+    hipLaunchKernelGGL(refine_kernel<3>, dim3(rgrid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
                        s.hist);
-    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl,
-                       s.hist, s.cand);
+    const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
+    const uint32_t cgrid = grid_for(n_tiles, 256, 256);
+    hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, st, s.keys, s.tmax, a.n_rows,
+                       s.ctl, s.hist, s.cand);
     return hipGetLastError();
 }
 

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256)
 scan_stream_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
                    const uint32_t* __restrict__ dead, uint32_t n_rows,
                    const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
-                   uint32_t* __restrict__ hist) {
+                   uint32_t* __restrict__ tmax, uint32_t* __restrict__ hist) {
     constexpr int RPW = 64 / G;   // rows per wave iteration
     constexpr int ITERS = G;      // iterations per 64-row tile
     constexpr int D4 = G * NV;    // float4 per row
@@ -110,14 +110,16 @@ scan_stream_kernel(const float* __restrict__ corpus, const float* __restrict__ q
         }
         // lane holds the score of tile row gl*RPW + sub
         const uint32_t row = row0 + (uint32_t)(gl * RPW + sub);
+        uint32_t key = 0u;
         if (row < n_rows) {
-            uint32_t key = 0u;
             if (!row_is_dead(dead, row)) {
                 key = score_key(mine);
                 atomicAdd(&lhist[key >> 21], 1u);
             }
             keys[row] = key;
         }
+        const uint32_t tm = wave_max_u32(key);
+        if (lane == 0) tmax[t] = tm;
     }
     __syncthreads();
     for (int i = tid; i < (int)HIST_BINS; i += 256) {
@@ -155,7 +157,7 @@ static void launch_one(const float* d_q, const ScanArgs& a, const Scratch& s, hi
     }
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL((scan_stream_kernel<METRIC, G, NV, U>), dim3(grid), dim3(256), 0, st,
-                       a.corpus, d_q, a.dead, a.n_rows, s.ctl, s.keys, s.hist);
+                       a.corpus, d_q, a.dead, a.n_rows, s.ctl, s.keys, s.tmax, s.hist);
 }
 
 template <int METRIC>
