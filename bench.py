@@ -84,30 +84,17 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
     esz = 4
+    ex = None
     if world > 1:
-        # per-step exchange buffers: [k scores | k global rows] per rank
-        pack = torch.zeros((n_q, 2 * k), dtype=torch.int32, device="cuda")
-        gathered = torch.zeros((n_q, world, 2 * k), dtype=torch.int32, device="cuda")
-        g_rows = torch.zeros((n_q, world, k), dtype=torch.int32, device="cuda")
-        g_scores = torch.zeros((n_q, world, k), dtype=torch.float32, device="cuda")
-        m_rows = torch.zeros((n_q, k), dtype=torch.int32, device="cuda")
-        m_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
-        m_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+        from trueno_rag_amd.sharded import ShardExchange
+        ex = ShardExchange(k, slots=n_q, device=torch.device("cuda", local))
 
     def step(i):
         store.search_device(Q.data_ptr() + i * d * esz, 1, k, out_rows.data_ptr() + i * k * esz,
                             out_scores.data_ptr() + i * k * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
-        if world > 1:
-            pack[i, :k] = out_scores[i].view(torch.int32)
-            pack[i, k:] = out_rows[i] + row0
-            dist.all_gather_into_tensor(gathered[i], pack[i])
-            g_scores[i] = gathered[i, :, :k].view(torch.float32)
-            g_rows[i] = gathered[i, :, k:]
-            pkg._abi.check(L.trag_merge_topk_device(
-                C.c_void_p(g_rows[i].data_ptr()), C.c_void_p(g_scores[i].data_ptr()), None, world, k, k,
-                C.c_void_p(m_rows[i].data_ptr()), C.c_void_p(m_scores[i].data_ptr()),
-                C.c_void_p(m_n[i].data_ptr()), C.c_void_p(sptr)))
+        if ex is not None:  # one all-gather of (scores, global rows, count) + device merge
+            ex.exchange(i, out_rows[i], out_scores[i], out_n[i], row0, sptr)
 
     def fence():
         torch.cuda.synchronize()
@@ -133,8 +120,8 @@ def main():
 
     # ---- parity at full size (outside the timed region) ----
     uncertified = int((status[args.warmup:] != 0).sum().item())
-    final_rows = (m_rows if world > 1 else out_rows)[-1].cpu().numpy().astype(np.uint32)
-    final_scores = (m_scores if world > 1 else out_scores)[-1].cpu().numpy()
+    final_rows = (ex.out_rows if ex is not None else out_rows)[-1].cpu().numpy().astype(np.uint32)
+    final_scores = (ex.out_scores if ex is not None else out_scores)[-1].cpu().numpy()
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
     if world == 1:
         # the exact-order scan of the same query must return the same rows and score bits

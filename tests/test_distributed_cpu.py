@@ -1,0 +1,88 @@
+"""CPU, world size 2 (gloo): the sharded path's exchange step — shard ranges,
+all-gather of per-shard top-k with global rows, merge — against a single
+global oracle search. The per-shard lists come from the oracle (no GPU here);
+on a GPU box the same ShardExchange runs over RCCL (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, d, k, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_package
+    from oracle import oracle
+    pkg = load_package()
+    from trueno_rag_amd.sharded import ShardExchange, shard_range
+    row0, n_local = shard_range(rank, world, n_total)
+    corpus = oracle.synth_rows(4242, row0, n_local, d)           # this rank's slice of the global corpus
+    corpus_dup = corpus.copy()
+    queries = oracle.synth_rows(4343, 0, 3, d)
+    ex = ShardExchange(k, slots=3)
+    results = []
+    for qi in range(3):
+        r, s = oracle.search(corpus_dup, queries[qi], k, 0)
+        lr = torch.zeros(k, dtype=torch.int32)
+        ls = torch.zeros(k, dtype=torch.float32)
+        lr[:len(r)] = torch.from_numpy(r.astype(np.int32))
+        ls[:len(s)] = torch.from_numpy(s)
+        o_r, o_s, o_n = ex.exchange(qi, lr, ls, len(r), row0)
+        results.append((o_r.numpy().copy(), o_s.numpy().copy(), int(o_n)))
+    out_q.put((rank, results))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,k", [(5000, 10), (7, 10), (1001, 50)])
+def test_two_rank_exchange_matches_global_search(oracle, n_total, k):
+    world, d = 2, 64
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, d, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    corpus = oracle.synth_rows(4242, 0, n_total, d)
+    queries = oracle.synth_rows(4343, 0, 3, d)
+    for qi in range(3):
+        er, es = oracle.search(corpus, queries[qi], k, 0)
+        for rank in range(world):
+            r, s, n = got[rank][qi]
+            assert n == len(er)
+            assert r[:n].astype(np.uint32).tolist() == er.tolist(), f"rank {rank} query {qi}"
+            assert s[:n].tobytes() == es.tobytes()
+
+
+def test_shard_ranges_cover_everything(trag):
+    from trueno_rag_amd.sharded import shard_range
+    for n in (0, 1, 7, 8, 10_000_000, 1_000_001):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(r, world, n) for r in range(world)]
+            assert sum(c for _, c in spans) == n
+            pos = 0
+            for r0, c in spans:
+                assert r0 == min(pos, n) or c == 0
+                pos += c
