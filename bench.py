@@ -35,7 +35,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows (whole job)")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan")
+    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 matrix cores")
+    ap.add_argument("--batch", type=int, default=1, help="queries per step (>= 8: matrix-core path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     return ap.parse_args()
@@ -75,7 +76,8 @@ def main():
                                                   reserve_rows=n_local))
     store.fill_synthetic(n_local, seed, first_global_row=row0)
 
-    n_q = args.steps + args.warmup
+    B = args.batch
+    n_q = (args.steps + args.warmup) * B
     Q = torch.from_numpy(unit_queries(n_q, d, seed + 100)).cuda()
     out_rows = torch.zeros((n_q, k), dtype=torch.int32, device="cuda")
     out_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
@@ -89,12 +91,14 @@ def main():
         from trueno_rag_amd.sharded import ShardExchange
         ex = ShardExchange(k, slots=n_q, device=torch.device("cuda", local))
 
-    def step(i):
-        store.search_device(Q.data_ptr() + i * d * esz, 1, k, out_rows.data_ptr() + i * k * esz,
+    def step(s):
+        i = s * B
+        store.search_device(Q.data_ptr() + i * d * esz, B, k, out_rows.data_ptr() + i * k * esz,
                             out_scores.data_ptr() + i * k * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
-        if ex is not None:  # one all-gather of (scores, global rows, count) + device merge
-            ex.exchange(i, out_rows[i], out_scores[i], out_n[i], row0, sptr)
+        if ex is not None:  # one all-gather of (scores, global rows, count) + device merge per query
+            for j in range(i, i + B):
+                ex.exchange(j, out_rows[j], out_scores[j], out_n[j], row0, sptr)
 
     def fence():
         torch.cuda.synchronize()
@@ -107,7 +111,7 @@ def main():
     fence()
     store.set_profiling(True)
     t0 = time.perf_counter()
-    for i in range(args.warmup, n_q):
+    for i in range(args.warmup, args.warmup + args.steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
@@ -119,7 +123,7 @@ def main():
         elapsed = float(t.item())
 
     # ---- parity at full size (outside the timed region) ----
-    uncertified = int((status[args.warmup:] != 0).sum().item())
+    uncertified = int((status[args.warmup * B:] != 0).sum().item())
     final_rows = (ex.out_rows if ex is not None else out_rows)[-1].cpu().numpy().astype(np.uint32)
     final_scores = (ex.out_scores if ex is not None else out_scores)[-1].cpu().numpy()
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
@@ -136,9 +140,12 @@ def main():
         scan_avg_ms = scan_ms / max(scan_launches, 1)
         algo_bytes = float(n_local) * d * 4.0  # bytes of corpus one scan launch must read
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
+        flops = 2.0 * B * n_local * d
+        tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
+        mfma_bound = B >= 40  # 2*B*N*d flops over N*d*4 bytes vs 157.3 TF / 8 TB/s = 19.7 flop/B
         result = {
             "metric": "queries/sec, brute-force cosine top-10 over N x d fp32 (achieved HBM GB/s in roofline)",
-            "value": args.steps / elapsed,
+            "value": args.steps * B / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -149,17 +156,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{n_total}x{d} fp32 corpus in HBM, single-query cosine top-{k} per step",
-                       "rows": n_total, "dim": d, "k": k, "batch": 1, "metric": "cosine",
+            "config": {"workload": f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, cosine top-{k}",
+                       "rows": n_total, "dim": d, "k": k, "batch": B, "metric": "cosine",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
-                       "scan_mode": {0: "auto", 1: "exact", 2: "stream"}[args.mode]},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "scan (corpus pass)", "kernel_avg_ms": scan_avg_ms,
-                         "launches_timed": scan_launches, "algorithmic_bytes_per_launch": algo_bytes,
-                         "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9},
+                       "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma"}[args.mode]},
+            "roofline": ({"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
+                          "frac": tflops / 157.3, "traffic": None, "flops_per_launch": flops}
+                         if mfma_bound else
+                         {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved / HBM_PEAK_GBS, "traffic": None}),
+
             "parity": parity,
         }
+        result["roofline"].update({"kernel": "scan (corpus pass)", "kernel_avg_ms": scan_avg_ms,
+                                   "launches_timed": scan_launches, "algorithmic_bytes_per_launch": algo_bytes,
+                                   "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9})
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(store, Q, n_local, n_total, d, k, args.cpu_sample_rows,
                                                   final_rows if world == 1 else None)

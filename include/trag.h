@@ -52,7 +52,9 @@ typedef enum trag_metric { TRAG_COSINE = 0, TRAG_EUCLIDEAN = 1, TRAG_DOT_PRODUCT
 typedef enum trag_scan_mode {
     TRAG_SCAN_AUTO = 0,
     TRAG_SCAN_EXACT = 1,  /* every row scored with the reference's sequential f32 order */
-    TRAG_SCAN_STREAM = 2  /* reassociated streaming scan + exact re-score of candidates */
+    TRAG_SCAN_STREAM = 2, /* reassociated streaming scan + exact re-score of candidates */
+    TRAG_SCAN_MFMA = 3    /* query batches as Q x D^T on the matrix cores + exact re-score
+                             (cosine / dot product, dim % 32 == 0); AUTO picks it for >= 8 queries */
 } trag_scan_mode;
 
 /* VectorStoreConfig, src/index.rs:283-307 (the hnsw_* fields are never read by

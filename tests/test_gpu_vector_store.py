@@ -370,3 +370,64 @@ def test_hybrid_retriever_path(trag, oracle):
     assert [chunks.index(r.chunk) for r in dres] == er[:5].tolist()
     dr = trag.DenseRetriever.new(hr.dense_store(), Emb())
     assert [chunks.index(r.chunk) for r in dr.retrieve("42", 5)] == er[:5].tolist()
+
+
+# ---------------- batched queries on the matrix cores ----------------
+
+MFMA = 3
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("n,d,B", [(50_000, 768, 40), (33_333, 384, 130), (20_000, 128, 300)])
+def test_batch_mfma_parity(trag, oracle, n, d, B, metric):
+    rng = np.random.default_rng(n + d + B)
+    corpus = unit_rows(rng, n, d) if metric == 0 else rng.standard_normal((n, d)).astype(np.float32)
+    corpus[17] = corpus[n - 5]            # duplicate rows across tiles
+    corpus[1000] = 0.0                    # zero-norm row
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[3] = corpus[17]                     # a query with an exact tie at the top
+    Q[5] = 0.0                            # zero query
+    store = make_store(trag, d, metric, MFMA)
+    store.insert_rows(corpus)
+    dead = np.zeros(n, dtype=np.uint8)
+    for r in (5, 64, 12_345):
+        store.remove_row(r)
+        dead[r] = 1
+    for k in (10, 50):
+        rows, scores, cnt = store.search_batch_rows(Q, k)
+        assert cnt.tolist() == [k] * B
+        for b in range(B):
+            er, es = oracle.search(corpus, Q[b], k, metric, dead=dead)
+            assert_same_ranking(rows[b], scores[b], er, es, f"mfma batch n={n} d={d} q={b} k={k} metric={metric}")
+    st = store.last_stats()
+    assert st["mode_used"] == MFMA
+    # the zero query ties every row at 0.0: it cannot be certified and is repeated exactly
+    assert st["fallbacks"] <= 2
+
+
+def test_batch_auto_mode_uses_mfma_from_8_queries(trag, oracle):
+    n, d = 30_000, 384
+    store = make_store(trag, d, 0, 0, reserve=n)
+    store.fill_synthetic(n, 77)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(78, 0, 9, d)
+    rows, scores, cnt = store.search_batch_rows(Q, 10)
+    assert store.last_stats()["mode_used"] == MFMA
+    for b in range(9):
+        er, es = oracle.search(corpus, Q[b], 10, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"auto batch {b}")
+    rows, scores, cnt = store.search_batch_rows(Q[:3], 10)
+    assert store.last_stats()["mode_used"] == EXACT
+
+
+def test_batch_euclidean_falls_back_to_exact_scans(trag, oracle):
+    n, d, B = 8000, 128, 12
+    rng = np.random.default_rng(12)
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    store = make_store(trag, d, 1, 0)
+    store.insert_rows(corpus)
+    rows, scores, _ = store.search_batch_rows(Q, 10)
+    for b in range(B):
+        er, es = oracle.search(corpus, Q[b], 10, 1)
+        assert_same_ranking(rows[b], scores[b], er, es, f"euclid batch {b}")

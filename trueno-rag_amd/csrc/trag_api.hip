@@ -59,6 +59,10 @@ struct trag_store {
     uint32_t* d_dead = nullptr;    // bitmap, (cap_rows + 31) / 32 words
     std::vector<uint32_t> h_dead;  // host mirror
     float* d_vmax_sq = nullptr;    // 1 float
+    float* d_norm2 = nullptr;      // cap_rows squared row norms (batched cosine epilogue)
+    BatchScratch batch{};
+    uint64_t batch_rows_cap = 0;   // rows the batch scratch was sized for
+    uint32_t batch_q_cap = 0;
     // search scratch (one query in flight per handle)
     Scratch scratch{};
     uint64_t keys_cap = 0;
@@ -89,6 +93,7 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
     cap = (cap + 63) & ~63ull;
     float* nrows = nullptr;
     uint32_t* ndead = nullptr;
+    float* nnorm = nullptr;
     const size_t row_bytes = (size_t)cap * s->cfg.dim * sizeof(float);
     const size_t dead_words = (size_t)(cap + 31) / 32;
     HIP_TRY(hipMalloc(&nrows, row_bytes));
@@ -97,8 +102,16 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
         (void)hipFree(nrows);
         return fail(TRAG_OOM, std::string("hipMalloc(dead bitmap): ") + hipGetErrorString(e));
     }
+    e = hipMalloc(&nnorm, (size_t)cap * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nrows);
+        (void)hipFree(ndead);
+        return fail(TRAG_OOM, std::string("hipMalloc(row norms): ") + hipGetErrorString(e));
+    }
     HIP_TRY(hipMemsetAsync(ndead, 0, dead_words * sizeof(uint32_t), s->stream));
     if (s->n_rows) {
+        HIP_TRY(hipMemcpyAsync(nnorm, s->d_norm2, (size_t)s->n_rows * sizeof(float),
+                               hipMemcpyDeviceToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(nrows, s->d_rows, (size_t)s->n_rows * s->cfg.dim * sizeof(float),
                                hipMemcpyDeviceToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(ndead, s->d_dead, ((size_t)(s->n_rows + 31) / 32) * sizeof(uint32_t),
@@ -107,8 +120,10 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_dead) (void)hipFree(s->d_dead);
+    if (s->d_norm2) (void)hipFree(s->d_norm2);
     s->d_rows = nrows;
     s->d_dead = ndead;
+    s->d_norm2 = nnorm;
     s->cap_rows = cap;
     s->h_dead.resize(dead_words, 0u);
     return TRAG_OK;
@@ -160,11 +175,42 @@ trag_status ensure_staging(trag_store* s, uint64_t nq, uint64_t k) {
     return TRAG_OK;
 }
 
+trag_status ensure_batch_scratch(trag_store* s, uint32_t nq) {
+    const uint32_t qcap = std::min<uint32_t>(std::max<uint32_t>(nq, 1), BATCH_QUERIES);
+    if (s->batch.keys && s->batch_rows_cap >= s->cap_rows && s->batch_q_cap >= qcap) return TRAG_OK;
+    void* old[] = {s->batch.qpad, s->batch.ctls, s->batch.keys, s->batch.tmax, s->batch.cand};
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    s->batch = BatchScratch{};
+    s->batch_rows_cap = 0;
+    s->batch_q_cap = 0;
+    const uint32_t qalloc = std::max(qcap, s->batch_q_cap);
+    const size_t qpad_rows = ((size_t)qalloc + 127) / 128 * 128;
+    s->batch.keys_stride = (size_t)s->cap_rows;
+    s->batch.tmax_stride = (size_t)s->cap_rows / 64 + 1;
+    HIP_TRY(hipMalloc(&s->batch.qpad, qpad_rows * s->cfg.dim * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->batch.ctls, (size_t)qalloc * sizeof(SearchCtl)));
+    HIP_TRY(hipMalloc(&s->batch.keys, (size_t)qalloc * s->batch.keys_stride * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->batch.tmax, (size_t)qalloc * s->batch.tmax_stride * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->batch.cand, (size_t)qalloc * CAND_CAP * sizeof(uint32_t)));
+    s->batch_rows_cap = s->cap_rows;
+    s->batch_q_cap = qalloc;
+    return TRAG_OK;
+}
+
+// Batches go to the matrix cores when the mode asks for it, or by default from
+// 8 queries up, if the metric/dimension have a kernel and the corpus is not tiny.
+bool use_batch_path(const trag_store* s, uint32_t mode, uint32_t nq) {
+    if (!batch_supports(s->cfg.dim, s->cfg.metric) || s->n_rows < 4096) return false;
+    if (mode == TRAG_SCAN_MFMA) return true;
+    return mode == TRAG_SCAN_AUTO && nq >= 8;
+}
+
 uint32_t pick_mode(const trag_store* s, uint32_t requested) {
     uint32_t mode = requested;
     // The exact-order scan measured faster than the streaming one on MI355X (it
     // needs no re-score), so it is the default for every dimension.
-    if (mode == TRAG_SCAN_AUTO) mode = TRAG_SCAN_EXACT;
+    if (mode == TRAG_SCAN_AUTO || mode == TRAG_SCAN_MFMA) mode = TRAG_SCAN_EXACT;
     if (mode == TRAG_SCAN_STREAM && !stream_supports_dim(s->cfg.dim)) mode = TRAG_SCAN_EXACT;
     return mode;
 }
@@ -178,6 +224,37 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     if (ts != TRAG_OK) return ts;
     const uint32_t live = (uint32_t)s->n_live;
     const uint32_t k_eff = std::min<uint32_t>(k, live);
+    if (mode == TRAG_SCAN_MFMA) {
+        const uint32_t need_b = (uint32_t)std::min<uint64_t>((uint64_t)k_eff + STREAM_SLACK, live);
+        if (need_b > CAND_CAP) return fail(TRAG_UNSUPPORTED, "k exceeds the single-workgroup final sort");
+        ts = ensure_batch_scratch(s, n_queries);
+        if (ts != TRAG_OK) return ts;
+        ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+        for (uint32_t b0 = 0; b0 < n_queries; b0 += BATCH_QUERIES) {
+            const uint32_t nb = std::min<uint32_t>(BATCH_QUERIES, n_queries - b0);
+            const float* Qb = d_queries + (size_t)b0 * s->cfg.dim;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (s->profiling && s->ev_used < 4096) {
+                if (s->ev_used == s->ev_pool.size()) {
+                    hipEvent_t a0, a1;
+                    HIP_TRY(hipEventCreate(&a0));
+                    HIP_TRY(hipEventCreate(&a1));
+                    s->ev_pool.emplace_back(a0, a1);
+                }
+                e0 = s->ev_pool[s->ev_used].first;
+                e1 = s->ev_pool[s->ev_used].second;
+                s->ev_used += 1;
+                HIP_TRY(hipEventRecord(e0, st));
+            }
+            HIP_TRY(launch_batch_scan(Qb, nb, a, s->d_norm2, s->batch, need_b, k_eff, s->d_vmax_sq, st));
+            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(launch_batch_finish(Qb, nb, a, s->batch, live, k, d_out_rows + (size_t)b0 * k,
+                                        d_out_scores + (size_t)b0 * k, d_out_n + b0,
+                                        d_status ? d_status + b0 : nullptr, st));
+        }
+        s->stats.mode_used = mode;
+        return TRAG_OK;
+    }
     const bool rescore = mode == TRAG_SCAN_STREAM;
     uint64_t need64 = rescore ? (uint64_t)k_eff + STREAM_SLACK : k_eff;
     const uint32_t need = (uint32_t)std::min<uint64_t>(need64, live);
@@ -226,7 +303,7 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
     *out = nullptr;
     if (cfg->dim == 0) return fail(TRAG_INVALID_CONFIG, "dimension must be positive");
     if (cfg->metric > TRAG_DOT_PRODUCT) return fail(TRAG_INVALID_CONFIG, "unknown metric");
-    if (cfg->scan_mode > TRAG_SCAN_STREAM) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    if (cfg->scan_mode > TRAG_SCAN_MFMA) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -258,7 +335,8 @@ void trag_store_destroy(trag_store* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->scratch.ctl, s->scratch.hist,
+    void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->batch.qpad, s->batch.ctls,
+                    s->batch.keys, s->batch.tmax, s->batch.cand, s->scratch.ctl, s->scratch.hist,
                     s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->d_q, s->d_out_rows, s->d_out_scores,
                     s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
@@ -298,7 +376,7 @@ trag_status trag_store_insert(trag_store* s, const float* rows, uint64_t n, uint
     if (ts != TRAG_OK) return ts;
     float* dst = s->d_rows + (size_t)s->n_rows * dim;
     HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(launch_update_vmax(dst, n, dim, s->d_vmax_sq, s->stream));
+    HIP_TRY(launch_update_vmax(dst, n, dim, s->d_vmax_sq, s->d_norm2 + s->n_rows, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->n_rows += n;
     s->n_live += n;
@@ -317,7 +395,7 @@ trag_status trag_store_overwrite(trag_store* s, uint32_t row, const float* vec, 
     DeviceGuard guard(s->device);
     float* dst = s->d_rows + (size_t)row * dim;
     HIP_TRY(hipMemcpyAsync(dst, vec, (size_t)dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(launch_update_vmax(dst, 1, dim, s->d_vmax_sq, s->stream));
+    HIP_TRY(launch_update_vmax(dst, 1, dim, s->d_vmax_sq, s->d_norm2 + row, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return TRAG_OK;
 }
@@ -349,7 +427,7 @@ trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
     HIP_TRY(hipMalloc(&d_norm, (size_t)n * sizeof(float)));
     float* dst = s->d_rows + (size_t)s->n_rows * s->cfg.dim;
     hipError_t e = launch_fill_synthetic(dst, first_global_row, n, s->cfg.dim, seed, d_norm, s->stream);
-    if (e == hipSuccess) e = launch_update_vmax(dst, n, s->cfg.dim, s->d_vmax_sq, s->stream);
+    if (e == hipSuccess) e = launch_update_vmax(dst, n, s->cfg.dim, s->d_vmax_sq, s->d_norm2 + s->n_rows, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     (void)hipFree(d_norm);
     if (e != hipSuccess) return fail(TRAG_DEVICE_ERROR, std::string("fill_synthetic: ") + hipGetErrorString(e));
@@ -387,8 +465,10 @@ trag_status trag_store_search_device(trag_store* s, const float* d_queries, uint
         if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, n_queries * sizeof(uint32_t), st));
         return TRAG_OK;
     }
-    return enqueue_search(s, d_queries, n_queries, k, pick_mode(s, s->cfg.scan_mode), d_out_rows,
-                          d_out_scores, d_out_n, d_status, st);
+    const uint32_t mode = use_batch_path(s, s->cfg.scan_mode, n_queries) ? (uint32_t)TRAG_SCAN_MFMA
+                                                                          : pick_mode(s, s->cfg.scan_mode);
+    return enqueue_search(s, d_queries, n_queries, k, mode, d_out_rows, d_out_scores, d_out_n,
+                          d_status, st);
 }
 
 trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_t n_queries,
@@ -412,7 +492,8 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
     hipStream_t st = s->stream;
     HIP_TRY(hipMemcpyAsync(s->d_q, queries, (size_t)n_queries * dim * sizeof(float),
                            hipMemcpyHostToDevice, st));
-    uint32_t mode = pick_mode(s, s->cfg.scan_mode);
+    uint32_t mode = use_batch_path(s, s->cfg.scan_mode, n_queries) ? (uint32_t)TRAG_SCAN_MFMA
+                                                                   : pick_mode(s, s->cfg.scan_mode);
     ts = enqueue_search(s, s->d_q, n_queries, k, mode, s->d_out_rows, s->d_out_scores, s->d_out_n,
                         s->d_out_status, st);
     if (ts != TRAG_OK) return ts;
@@ -427,7 +508,7 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     s->stats.fallbacks = 0;
-    if (mode == TRAG_SCAN_STREAM) {
+    if (mode == TRAG_SCAN_STREAM || mode == TRAG_SCAN_MFMA) {
         // Repeat, with the exact scan, every query whose ranking could not be certified.
         for (uint32_t b = 0; b < n_queries; ++b) {
             if (status[b] == ST_OK) continue;
@@ -443,12 +524,19 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
             HIP_TRY(hipMemcpyAsync(out_n + b, s->d_out_n + b, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
-        s->stats.mode_used = TRAG_SCAN_STREAM;
+        s->stats.mode_used = mode;
     }
-    SearchCtl ctl;
-    HIP_TRY(hipMemcpy(&ctl, s->scratch.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
-    s->stats.candidates = ctl.expect;
-    s->stats.refine_levels = ctl.resolved ? ctl.resolved : 3;
+    if (mode == TRAG_SCAN_MFMA) {
+        SearchCtl ctl;
+        HIP_TRY(hipMemcpy(&ctl, s->batch.ctls, sizeof(ctl), hipMemcpyDeviceToHost));
+        s->stats.candidates = ctl.cand_count;
+        s->stats.refine_levels = 0;
+    } else {
+        SearchCtl ctl;
+        HIP_TRY(hipMemcpy(&ctl, s->scratch.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+        s->stats.candidates = ctl.expect;
+        s->stats.refine_levels = ctl.resolved ? ctl.resolved : 3;
+    }
     return TRAG_OK;
 }
 
@@ -459,7 +547,7 @@ trag_status trag_store_search(trag_store* s, const float* query, uint32_t dim, u
 
 trag_status trag_store_set_scan_mode(trag_store* s, uint32_t scan_mode) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
-    if (scan_mode > TRAG_SCAN_STREAM) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    if (scan_mode > TRAG_SCAN_MFMA) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
     std::lock_guard<std::mutex> lk(s->mu);
     s->cfg.scan_mode = scan_mode;
     return TRAG_OK;

@@ -1,0 +1,359 @@
+// Batched queries on gfx950: Q x D^T on the fp32 matrix cores with a fused
+// scoring epilogue, then per-query threshold selection from tile maxima.
+//
+// For B queries the similarity matrix is a genuine GEMM (B x d times d x N),
+// compute-bound for B >~ 40 (2*B*N*d flops over N*d*4 bytes). The products are
+// exact fp32 (v_mfma_f32_32x32x2_f32 is a chain of fmaf), but the summation
+// order differs from the reference's left-to-right mul+add, so the scores
+// written here are approximations: as in the streaming single-query mode the
+// final stage re-scores the selected candidates with the reference arithmetic
+// and certifies the result against a worst-case bound.
+#include "trag_device.h"
+#include "trag_internal.h"
+
+namespace trag {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int BT_M = 128;        // queries per workgroup tile
+constexpr int BT_N = 128;        // corpus rows per workgroup tile
+constexpr int BT_K = 32;         // k-step staged through LDS
+constexpr int BT_LD = BT_K + 4;  // padded LDS row stride (floats): conflict-free b128 reads
+
+// prep for a block of queries: one workgroup per query computes ||q|| in the
+// reference's order and resets that query's control block.
+__global__ void __launch_bounds__(256)
+prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict__ ctls,
+                  uint32_t need, uint32_t k, const float* __restrict__ vmax_sq) {
+    __shared__ __attribute__((aligned(16))) float qs[4096];
+    const int tid = threadIdx.x;
+    const float* q = Q + (size_t)blockIdx.x * d;
+    SearchCtl* ctl = ctls + blockIdx.x;
+    float acc = 0.0f;
+    for (uint32_t base = 0; base < d; base += 4096) {
+        const uint32_t len = min(4096u, d - base);
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += 256) qs[i] = q[base + i];
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t i = 0;
+            for (; i + 4 <= len; i += 4) {
+                const v4f x = *reinterpret_cast<const v4f*>(&qs[i]);
+                float p0 = x.x * x.x, p1 = x.y * x.y, p2 = x.z * x.z, p3 = x.w * x.w;
+                acc = acc + p0;
+                acc = acc + p1;
+                acc = acc + p2;
+                acc = acc + p3;
+            }
+            for (; i < len; ++i) {
+                float p = qs[i] * qs[i];
+                acc = acc + p;
+            }
+        }
+    }
+    if (tid == 0) {
+        ctl->na_sq = acc;
+        ctl->na = sqrtf(acc);
+        ctl->vmax_sq = vmax_sq ? *vmax_sq : 0.0f;
+        ctl->need = need;
+        ctl->k = k;
+        ctl->resolved = 1;  // the threshold comes from tau_select_kernel, not from histograms
+        ctl->b1 = ctl->above1 = ctl->b2 = ctl->above2 = 0;
+        ctl->t_key = 0;
+        ctl->cut_ties = 0;
+        ctl->tie_quota = 0;
+        ctl->above3 = 0;
+        ctl->expect = 0;
+        ctl->cand_count = 0;
+        ctl->status = ST_OK;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// GEMM scan. Workgroup tile 128 queries x 128 rows, 4 waves as 2 x 2, each
+// wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (4 x 16 accumulator registers).
+// MFMA roles: A = queries (tile rows), B = corpus rows (tile columns), so an
+// accumulator register holds one query for 32 consecutive corpus rows across
+// the lanes and the key stores are 128-byte runs.
+// Operands of v_mfma_f32_32x32x2_f32 are one float per lane:
+//   a = A[i = lane & 31][k = lane >> 5],  b = B[k = lane >> 5][j = lane & 31].
+// The 32 k-values of a staged step are assigned to the 16 MFMAs as
+// k = 16 * (lane >> 5) + s (s = MFMA index), the same for A and B, so each lane
+// reads its 16 operands as four contiguous ds_read_b128.
+// METRIC: 0 cosine, 2 dot product.
+// ---------------------------------------------------------------------------
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpad,
+                 const float* __restrict__ norm2, const uint32_t* __restrict__ dead,
+                 uint32_t n_rows, uint32_t d, uint32_t n_queries, uint32_t q_tiles,
+                 const SearchCtl* __restrict__ ctls, uint32_t* __restrict__ keys,
+                 size_t keys_stride, uint32_t* __restrict__ tmax, size_t tmax_stride) {
+    __shared__ __attribute__((aligned(16))) float As[BT_M * BT_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BT_N * BT_LD];
+    __shared__ float na_s[BT_M];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // Workgroups that share a corpus tile (different query tiles) get ids that
+    // are equal mod 8 and adjacent in dispatch order, so that the second read
+    // of the tile is served by the same XCD's L2.
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, i8 = b >> 3;
+    const uint32_t qt = i8 % q_tiles;
+    const uint32_t nt = (i8 / q_tiles) * 8u + xcd;
+    const uint32_t n_tiles128 = (n_rows + BT_N - 1) / BT_N;
+    if (nt >= n_tiles128) return;
+    const uint32_t q0 = qt * BT_M, n0 = nt * BT_N;
+
+    if (tid < BT_M) na_s[tid] = (q0 + tid < n_queries) ? ctls[q0 + tid].na : 0.0f;
+
+    // staging map: thread -> (row = tid/8 + 32*i, float4 column = tid%8)
+    const int srow = tid >> 3, scol = tid & 7;
+    const float* aptr[4];
+    const float* bptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        aptr[i] = Qpad + (size_t)(q0 + srow + 32 * i) * d + scol * 4;
+        const uint32_t r = min(n0 + (uint32_t)(srow + 32 * i), n_rows - 1u);
+        bptr[i] = corpus + (size_t)r * d + scol * 4;
+    }
+    v4f ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ra[i] = *reinterpret_cast<const v4f*>(aptr[i]);
+        rb[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i]));
+    }
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int frow = lane & 31, fk = (lane >> 5) * 16;
+    const uint32_t nk = d / BT_K;
+    for (uint32_t kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<v4f*>(&As[(srow + 32 * i) * BT_LD + scol * 4]) = ra[i];
+            *reinterpret_cast<v4f*>(&Bs[(srow + 32 * i) * BT_LD + scol * 4]) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[i] = *reinterpret_cast<const v4f*>(aptr[i] + (size_t)(kt + 1) * BT_K);
+                rb[i] = __builtin_nontemporal_load(
+                    reinterpret_cast<const v4f*>(bptr[i] + (size_t)(kt + 1) * BT_K));
+            }
+        }
+        v4f fa[2][4], fb[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fa[m][j] = *reinterpret_cast<const v4f*>(
+                    &As[(wm * 64 + m * 32 + frow) * BT_LD + fk + j * 4]);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[n][j] = *reinterpret_cast<const v4f*>(
+                    &Bs[(wn * 64 + n * 32 + frow) * BT_LD + fk + j * 4]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][j][e], fb[n][j][e],
+                                                                         acc[m][n], 0, 0, 0);
+    }
+
+    // ---- epilogue: scores -> ordered keys, per-(query, 64-row tile) maxima ----
+    const int half = lane >> 5;
+    uint32_t rows_[2];
+    float inv_nb[2];
+    bool live[2], ok_nb[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const uint32_t row = n0 + wn * 64 + n * 32 + (lane & 31);
+        rows_[n] = row;
+        live[n] = row < n_rows && !row_is_dead(dead, row);
+        float nb2 = 1.0f;
+        ok_nb[n] = true;
+        if (METRIC == 0) {
+            nb2 = row < n_rows ? norm2[row] : 0.0f;
+            // outside this range the error bound of the certification does not hold
+            ok_nb[n] = nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY);
+        }
+        inv_nb[n] = nb2 > 0.0f ? 1.0f / sqrtf(nb2) : 0.0f;
+    }
+    const uint32_t tile64 = (n0 + wn * 64) >> 6;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qi = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const uint32_t q = q0 + qi;
+            const float na = na_s[qi];
+            uint32_t kmax = 0u;
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float dot = acc[m][n][r];
+                float s;
+                if (METRIC == 0) {
+                    s = (na > 0.0f) ? dot * (inv_nb[n] / na) : 0.0f;
+                    if (!ok_nb[n]) s = INFINITY;
+                } else {
+                    s = dot;
+                }
+                if (!(fabsf(dot) < INFINITY)) s = INFINITY;  // overflow / NaN: always re-scored
+                const uint32_t key = live[n] ? score_key(s) : 0u;
+                if (q < n_queries && rows_[n] < n_rows) keys[q * keys_stride + rows_[n]] = key;
+                kmax = key > kmax ? key : kmax;
+            }
+            // max over the 32 lanes of this half (they hold the same query)
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) {
+                const uint32_t w = (uint32_t)__shfl_xor((int)kmax, o);
+                kmax = w > kmax ? w : kmax;
+            }
+            if ((lane & 31) == 0 && q < n_queries && (uint32_t)(n0 + wn * 64) < n_rows)
+                tmax[q * tmax_stride + tile64] = kmax;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Per-query threshold: the need-th largest tile maximum. At least `need` tiles
+// hold a key at or above it, hence at least `need` rows do, so the rows with
+// key >= tau contain the top `need`; because the best rows of a large corpus
+// almost always sit in different tiles, tau is close to the need-th best key.
+// One workgroup per query; three radix levels (11 + 11 + 10 bits) over the
+// query's tile maxima with workgroup-local histograms.
+// ---------------------------------------------------------------------------
+__device__ void find_bin256(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
+                            uint32_t* sh);  // defined below (LDS histogram variant)
+
+__global__ void __launch_bounds__(256)
+tau_select_kernel(const uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_t n_tiles,
+                  SearchCtl* __restrict__ ctls) {
+    __shared__ uint32_t lhist[HIST_BINS];
+    __shared__ uint32_t sh[8];
+    const int tid = threadIdx.x;
+    const uint32_t* tm = tmax + (size_t)blockIdx.x * tmax_stride;
+    SearchCtl* ctl = ctls + blockIdx.x;
+    uint32_t need = ctl->need;
+    if (need > n_tiles) {  // fewer tiles than wanted rows: take every live row
+        if (tid == 0) ctl->t_key = 1u;
+        return;
+    }
+    uint32_t prefix = 0, prefix_bits = 0;
+    const int shifts[3] = {21, 10, 0};
+    const uint32_t widths[3] = {11, 11, 10};
+    for (int level = 0; level < 3; ++level) {
+        for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
+        __syncthreads();
+        const uint32_t mshift = 32u - prefix_bits;
+        for (uint32_t i = tid; i < n_tiles; i += 256) {
+            const uint32_t v = tm[i];
+            const bool match = prefix_bits == 0 || (v >> mshift) == prefix;
+            if (match) atomicAdd(&lhist[(v >> shifts[level]) & ((1u << widths[level]) - 1u)], 1u);
+        }
+        __syncthreads();
+        uint32_t bin, above;
+        find_bin256(lhist, need, bin, above, sh);
+        need -= above;
+        prefix = (prefix << widths[level]) | bin;
+        prefix_bits += widths[level];
+        __syncthreads();
+    }
+    if (tid == 0) ctl->t_key = prefix > 1u ? prefix : 1u;
+}
+
+// find_bin over a histogram in LDS (same contract as the global-memory one).
+__device__ void find_bin256(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
+                            uint32_t* sh) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int top = (int)HIST_BINS - 1 - 8 * t;
+    uint32_t h[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { h[i] = hist[top - i]; sum += h[i]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) sh[w] = incl;
+    if (t == 0) { sh[4] = 0; sh[5] = 0; }
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < w; ++i) base += sh[i];
+    const uint32_t total = sh[0] + sh[1] + sh[2] + sh[3];
+    incl += base;
+    const uint32_t excl = incl - sum;
+    if (need > total) need = total;
+    if (need > 0 && excl < need && need <= incl) {
+        uint32_t cum = excl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (cum + h[i] >= need) { sh[4] = (uint32_t)(top - i); sh[5] = cum; break; }
+            cum += h[i];
+        }
+    }
+    __syncthreads();
+    bin = sh[4];
+    above = sh[5];
+}
+
+// Zero-padded copy of the query block (rows beyond n_queries are zero) so that
+// the GEMM tiles never read outside the buffer.
+__global__ void __launch_bounds__(256)
+pad_queries_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t padded, uint32_t d,
+                   float* __restrict__ out) {
+    const size_t total = (size_t)padded * d;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t q = e / d;
+        out[e] = q < n_queries ? Q[e] : 0.0f;
+    }
+}
+
+bool batch_supports(uint32_t dim, uint32_t metric) {
+    return (dim % BT_K) == 0 && (metric == TRAG_COSINE || metric == TRAG_DOT_PRODUCT);
+}
+
+hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a,
+                             const float* d_norm2, const BatchScratch& s, uint32_t need, uint32_t k,
+                             const float* d_vmax_sq, hipStream_t st) {
+    const uint32_t q_tiles = (n_queries + BT_M - 1) / BT_M;
+    const uint32_t padded = q_tiles * BT_M;
+    hipLaunchKernelGGL(pad_queries_kernel, dim3(std::min<uint32_t>(1024, (padded * a.dim + 255) / 256)),
+                       dim3(256), 0, st, d_Q, n_queries, padded, a.dim, s.qpad);
+    hipLaunchKernelGGL(prep_batch_kernel, dim3(n_queries), dim3(256), 0, st, d_Q, a.dim, s.ctls, need,
+                       k, d_vmax_sq);
+    const uint32_t n_tiles128 = (a.n_rows + BT_N - 1) / BT_N;
+    const uint32_t groups = (n_tiles128 + 7) / 8;  // corpus tiles in groups of 8 (one per XCD slot)
+    const uint32_t grid = groups * q_tiles * 8;
+    if (a.metric == TRAG_COSINE)
+        hipLaunchKernelGGL(gemm_scan_kernel<0>, dim3(grid), dim3(256), 0, st, a.corpus, s.qpad, d_norm2,
+                           a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys, s.keys_stride,
+                           s.tmax, s.tmax_stride);
+    else
+        hipLaunchKernelGGL(gemm_scan_kernel<2>, dim3(grid), dim3(256), 0, st, a.corpus, s.qpad, d_norm2,
+                           a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys, s.keys_stride,
+                           s.tmax, s.tmax_stride);
+    const uint32_t n_tiles64 = (a.n_rows + 63) / 64;
+    hipLaunchKernelGGL(tau_select_kernel, dim3(n_queries), dim3(256), 0, st, s.tmax, s.tmax_stride,
+                       n_tiles64, s.ctls);
+    return hipGetLastError();
+}
+
+}  // namespace trag

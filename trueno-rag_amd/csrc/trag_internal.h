@@ -49,6 +49,20 @@ struct Scratch {
     uint32_t* tmax;      // capacity rows / 64: largest key of each 64-row tile
 };
 
+// Device scratch of a block of queries on the batched (matrix-core) path.
+struct BatchScratch {
+    float* qpad;         // queries zero-padded to a multiple of 128 rows
+    SearchCtl* ctls;     // one per query
+    uint32_t* keys;      // [queries][keys_stride]
+    size_t keys_stride;
+    uint32_t* tmax;      // [queries][tmax_stride]
+    size_t tmax_stride;
+    uint32_t* cand;      // [queries][CAND_CAP]
+};
+
+constexpr uint32_t ST_OVERFLOW = 2;     // more candidates than the final sort holds: repeat exactly
+constexpr uint32_t BATCH_QUERIES = 256; // queries processed per batched pass
+
 struct ScanArgs {
     const float* corpus;
     const uint32_t* dead;  // tombstone bitmap, 1 bit per row
@@ -67,12 +81,21 @@ hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st);
 hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
                         uint32_t live, uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
                         uint32_t* d_status, hipStream_t st);
+// batched path (trag_batch.hip + the batched forms of compact/final)
+bool batch_supports(uint32_t dim, uint32_t metric);
+hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a,
+                             const float* d_norm2, const BatchScratch& s, uint32_t need, uint32_t k,
+                             const float* d_vmax_sq, hipStream_t st);
+hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanArgs& a,
+                               const BatchScratch& s, uint32_t live, uint32_t out_stride,
+                               uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
+                               uint32_t* d_status, hipStream_t st);
 hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint32_t dim,
                                  uint64_t seed, float* d_norm_tmp, hipStream_t st);
 hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_list_n,
                              uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t* d_out_rows,
                              float* d_out_scores, uint32_t* d_out_n, hipStream_t st);
 hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
-                              hipStream_t st);
+                              float* d_norm2_out, hipStream_t st);
 
 }  // namespace trag

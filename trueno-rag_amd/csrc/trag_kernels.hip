@@ -354,7 +354,12 @@ refine_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __r
 __global__ void __launch_bounds__(256)
 compact_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax, uint32_t n_rows,
                SearchCtl* __restrict__ ctl, const uint32_t* __restrict__ hist,
-               uint32_t* __restrict__ cand) {
+               uint32_t* __restrict__ cand, size_t keys_stride, size_t tmax_stride) {
+    // blockIdx.y = query of a batch (strides are 0 for a single query)
+    keys += (size_t)blockIdx.y * keys_stride;
+    tmax += (size_t)blockIdx.y * tmax_stride;
+    ctl += blockIdx.y;
+    cand += (size_t)blockIdx.y * CAND_CAP;
     __shared__ uint32_t sh[8];
     __shared__ uint32_t wcnt[4];
     __shared__ uint32_t taken_sh;
@@ -459,10 +464,25 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
              uint32_t d, uint32_t live, SearchCtl* __restrict__ ctl,
              const uint32_t* __restrict__ keys, const uint32_t* __restrict__ cand,
              uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
-             uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_status) {
+             uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_status,
+             size_t keys_stride, uint32_t out_stride, int use_count) {
     __shared__ unsigned long long sk[CAND_CAP];
     const int tid = threadIdx.x;
-    uint32_t C = ctl->expect;
+    {   // blockIdx.x = query of a batch (a single query launches one workgroup)
+        const uint32_t y = blockIdx.x;
+        q += (size_t)y * d;
+        ctl += y;
+        keys += (size_t)y * keys_stride;
+        cand += (size_t)y * CAND_CAP;
+        out_rows += (size_t)y * out_stride;
+        out_scores += (size_t)y * out_stride;
+        out_n += y;
+        if (out_status) out_status += y;
+    }
+    // use_count: the candidates were gathered against a given threshold and
+    // their number is only known from the append cursor
+    uint32_t C = use_count ? ctl->cand_count : ctl->expect;
+    const bool overflow = C > CAND_CAP;
     if (C > CAND_CAP) C = CAND_CAP;
     uint32_t P = 64;
     while (P < C) P <<= 1;
@@ -522,6 +542,7 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
             const float ek = key_score((uint32_t)(sk[n_out - 1] >> 32));
             if (!(ek > t + eps) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
         }
+        if (overflow) status = ST_OVERFLOW;
         ctl->status = status;
         if (out_status) *out_status = status;
     }
@@ -615,7 +636,7 @@ synth_fill_kernel(unsigned long long seed, unsigned long long row0, unsigned lon
 // 1e-3). One wave per row, coalesced.
 __global__ void __launch_bounds__(256)
 vmax_kernel(const float* __restrict__ rows, unsigned long long n, uint32_t d,
-            float* __restrict__ vmax_sq) {
+            float* __restrict__ vmax_sq, float* __restrict__ norm2_out) {
     const int lane = threadIdx.x & 63;
     const unsigned long long w0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) >> 6;
     const unsigned long long nw = ((unsigned long long)gridDim.x * 256ull) >> 6;
@@ -626,6 +647,7 @@ vmax_kernel(const float* __restrict__ rows, unsigned long long n, uint32_t d,
         for (uint32_t c = lane; c < d; c += 64) s = __builtin_fmaf(v[c], v[c], s);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0 && norm2_out) norm2_out[r] = s;  // squared norm, reassociated sum
         s = s * 1.001f;
         if (!(s < INFINITY)) continue;  // non-finite rows are always re-scored exactly
         best = fmaxf(best, s);
@@ -688,7 +710,7 @@ hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st) {
     const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
     const uint32_t cgrid = grid_for(n_tiles, 256, 256);
     hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, st, s.keys, s.tmax, a.n_rows,
-                       s.ctl, s.hist, s.cand);
+                       s.ctl, s.hist, s.cand, (size_t)0, (size_t)0);
     return hipGetLastError();
 }
 
@@ -699,11 +721,11 @@ static void final_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s
     if (rescore)
         hipLaunchKernelGGL((final_kernel<METRIC, true>), dim3(1), dim3(1024), 0, st, a.corpus, d_q,
                            a.n_rows, a.dim, live, s.ctl, s.keys, s.cand, d_out_rows, d_out_scores,
-                           d_out_n, d_status);
+                           d_out_n, d_status, (size_t)0, 0u, 0);
     else
         hipLaunchKernelGGL((final_kernel<METRIC, false>), dim3(1), dim3(1024), 0, st, a.corpus, d_q,
                            a.n_rows, a.dim, live, s.ctl, s.keys, s.cand, d_out_rows, d_out_scores,
-                           d_out_n, d_status);
+                           d_out_n, d_status, (size_t)0, 0u, 0);
 }
 
 hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
@@ -743,10 +765,32 @@ hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, cons
 }
 
 hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
-                              hipStream_t st) {
+                              float* d_norm2_out, hipStream_t st) {
     if (n == 0) return hipSuccess;
     const uint32_t grid = grid_for(n, 4, 256 * 8);
-    hipLaunchKernelGGL(vmax_kernel, dim3(grid), dim3(256), 0, st, d_rows, n, dim, d_vmax_sq);
+    hipLaunchKernelGGL(vmax_kernel, dim3(grid), dim3(256), 0, st, d_rows, n, dim, d_vmax_sq,
+                       d_norm2_out);
+    return hipGetLastError();
+}
+
+// Batched compaction and final stage: blockIdx.y / blockIdx.x select the query.
+hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanArgs& a,
+                               const BatchScratch& s, uint32_t live, uint32_t out_stride,
+                               uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
+                               uint32_t* d_status, hipStream_t st) {
+    const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
+    const uint32_t cgrid = grid_for(n_tiles, 256 * 4, 64);
+    hipLaunchKernelGGL(compact_kernel, dim3(cgrid, n_queries), dim3(256), 0, st, s.keys, s.tmax,
+                       a.n_rows, s.ctls, (const uint32_t*)nullptr, s.cand, s.keys_stride,
+                       s.tmax_stride);
+    if (a.metric == TRAG_COSINE)
+        hipLaunchKernelGGL((final_kernel<0, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,
+                           a.n_rows, a.dim, live, s.ctls, s.keys, s.cand, d_out_rows, d_out_scores,
+                           d_out_n, d_status, s.keys_stride, out_stride, 1);
+    else
+        hipLaunchKernelGGL((final_kernel<2, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,
+                           a.n_rows, a.dim, live, s.ctls, s.keys, s.cand, d_out_rows, d_out_scores,
+                           d_out_n, d_status, s.keys_stride, out_stride, 1);
     return hipGetLastError();
 }
 
