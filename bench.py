@@ -89,16 +89,19 @@ def main():
     ex = None
     if world > 1:
         from trueno_rag_amd.sharded import ShardExchange
-        ex = ShardExchange(k, slots=n_q, device=torch.device("cuda", local))
+        ex = ShardExchange(k, max_queries=B, device=torch.device("cuda", local))
+        m_rows = torch.zeros((n_q, k), dtype=torch.int32, device="cuda")
+        m_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
+        m_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
 
     def step(s):
         i = s * B
         store.search_device(Q.data_ptr() + i * d * esz, B, k, out_rows.data_ptr() + i * k * esz,
                             out_scores.data_ptr() + i * k * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
-        if ex is not None:  # one all-gather of (scores, global rows, count) + device merge per query
-            for j in range(i, i + B):
-                ex.exchange(j, out_rows[j], out_scores[j], out_n[j], row0, sptr)
+        if ex is not None:  # pack, ONE all-gather for the step's queries, device merge
+            ex.exchange(out_rows[i:i + B], out_scores[i:i + B], out_n[i:i + B], row0,
+                        m_rows[i:i + B], m_scores[i:i + B], m_n[i:i + B], sptr)
 
     def fence():
         torch.cuda.synchronize()
@@ -124,8 +127,8 @@ def main():
 
     # ---- parity at full size (outside the timed region) ----
     uncertified = int((status[args.warmup * B:] != 0).sum().item())
-    final_rows = (ex.out_rows if ex is not None else out_rows)[-1].cpu().numpy().astype(np.uint32)
-    final_scores = (ex.out_scores if ex is not None else out_scores)[-1].cpu().numpy()
+    final_rows = (m_rows if ex is not None else out_rows)[-1].cpu().numpy().astype(np.uint32)
+    final_scores = (m_scores if ex is not None else out_scores)[-1].cpu().numpy()
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
     if world == 1:
         # the exact-order scan of the same query must return the same rows and score bits

@@ -167,6 +167,19 @@ trag_status trag_merge_topk_device(const uint32_t *d_rows, const float *d_scores
                                    uint32_t k_out, uint32_t *d_out_rows, float *d_out_scores,
                                    uint32_t *d_out_n, void *hip_stream);
 
+/* Wire format of the cross-shard exchange, per query: k score bit patterns,
+ * k GLOBAL row ids, 1 count = 2k+1 32-bit words. trag_pack_topk_device writes
+ * n_queries such records from a search result (adding first_global_row to the
+ * local row ids); after an all-gather the receive buffer holds
+ * [n_lists][n_queries][2k+1] words and trag_merge_packed_device reduces it to
+ * the global top-k per query (same ordering rule as search). n_lists * k <= 4096. */
+trag_status trag_pack_topk_device(const uint32_t *d_rows, const float *d_scores, const uint32_t *d_n,
+                                  uint32_t first_global_row, uint32_t n_queries, uint32_t k,
+                                  uint32_t *d_packed, void *hip_stream);
+trag_status trag_merge_packed_device(const uint32_t *d_gathered, uint32_t n_lists,
+                                     uint32_t n_queries, uint32_t k, uint32_t *d_out_rows,
+                                     float *d_out_scores, uint32_t *d_out_n, void *hip_stream);
+
 /* Change the scan mode of later searches (trag_scan_mode). */
 trag_status trag_store_set_scan_mode(trag_store *s, uint32_t scan_mode);
 

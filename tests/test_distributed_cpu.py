@@ -37,16 +37,20 @@ def _worker(rank, world, port, n_total, d, k, out_q):
     corpus = oracle.synth_rows(4242, row0, n_local, d)           # this rank's slice of the global corpus
     corpus_dup = corpus.copy()
     queries = oracle.synth_rows(4343, 0, 3, d)
-    ex = ShardExchange(k, slots=3)
-    results = []
+    ex = ShardExchange(k, max_queries=3)
+    lr = torch.zeros((3, k), dtype=torch.int32)
+    ls = torch.zeros((3, k), dtype=torch.float32)
+    ln = torch.zeros(3, dtype=torch.int32)
     for qi in range(3):
         r, s = oracle.search(corpus_dup, queries[qi], k, 0)
-        lr = torch.zeros(k, dtype=torch.int32)
-        ls = torch.zeros(k, dtype=torch.float32)
-        lr[:len(r)] = torch.from_numpy(r.astype(np.int32))
-        ls[:len(s)] = torch.from_numpy(s)
-        o_r, o_s, o_n = ex.exchange(qi, lr, ls, len(r), row0)
-        results.append((o_r.numpy().copy(), o_s.numpy().copy(), int(o_n)))
+        lr[qi, :len(r)] = torch.from_numpy(r.astype(np.int32))
+        ls[qi, :len(s)] = torch.from_numpy(s)
+        ln[qi] = len(r)
+    o_r = torch.zeros((3, k), dtype=torch.int32)
+    o_s = torch.zeros((3, k), dtype=torch.float32)
+    o_n = torch.zeros(3, dtype=torch.int32)
+    ex.exchange(lr, ls, ln, row0, o_r, o_s, o_n)          # one all-gather for the whole batch
+    results = [(o_r[qi].numpy().copy(), o_s[qi].numpy().copy(), int(o_n[qi])) for qi in range(3)]
     out_q.put((rank, results))
     dist.barrier()
     dist.destroy_process_group()

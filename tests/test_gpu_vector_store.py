@@ -431,3 +431,49 @@ def test_batch_euclidean_falls_back_to_exact_scans(trag, oracle):
     for b in range(B):
         er, es = oracle.search(corpus, Q[b], 10, 1)
         assert_same_ranking(rows[b], scores[b], er, es, f"euclid batch {b}")
+
+
+# ---------------- cross-shard exchange kernels (one GPU stands in for two shards) ----------------
+
+def test_two_shards_on_one_gpu_merge_to_global_topk(trag, oracle):
+    import ctypes as C
+    import torch
+    from trueno_rag_amd.sharded import ShardExchange, shard_range
+    n_total, d, B, k = 40_001, 384, 5, 10
+    corpus = oracle.synth_rows(9001, 0, n_total, d)
+    corpus[39_000] = corpus[10]                       # exact tie across the shard boundary
+    Q = np.ascontiguousarray(np.concatenate([oracle.synth_rows(9002, 0, B - 1, d), corpus[10:11]]))
+    rec = 2 * k + 1
+    gathered = torch.zeros((2, B, rec), dtype=torch.int32, device="cuda")
+    L = trag.lib()
+    stores = []
+    for rank in range(2):
+        row0, n_local = shard_range(rank, 2, n_total)
+        st = make_store(trag, d, 0, EXACT)
+        st.insert_rows(corpus[row0:row0 + n_local])
+        stores.append(st)
+        rows, scores, cnt = st.search_batch_rows(Q, k)
+        d_rows = torch.from_numpy(rows.astype(np.int32)).cuda()
+        d_scores = torch.from_numpy(scores).cuda()
+        d_n = torch.from_numpy(cnt.astype(np.int32)).cuda()
+        assert L.trag_pack_topk_device(C.c_void_p(d_rows.data_ptr()), C.c_void_p(d_scores.data_ptr()),
+                                       C.c_void_p(d_n.data_ptr()), row0, B, k,
+                                       C.c_void_p(gathered[rank].data_ptr()), None) == 0
+    out_r = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+    out_s = torch.zeros((B, k), dtype=torch.float32, device="cuda")
+    out_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    assert L.trag_merge_packed_device(C.c_void_p(gathered.data_ptr()), 2, B, k, C.c_void_p(out_r.data_ptr()),
+                                      C.c_void_p(out_s.data_ptr()), C.c_void_p(out_n.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    for b in range(B):
+        er, es = oracle.search(corpus, Q[b], k, 0)
+        assert_same_ranking(out_r[b].cpu().numpy().astype(np.uint32), out_s[b].cpu().numpy(), er, es, f"merge {b}")
+    # world size 1 through the host class: the exchange is the identity plus the row offset
+    ex = ShardExchange(k, max_queries=B, device=torch.device("cuda"))
+    rows, scores, cnt = stores[0].search_batch_rows(Q, k)
+    o_r, o_s, o_n = torch.zeros_like(out_r), torch.zeros_like(out_s), torch.zeros_like(out_n)
+    ex.exchange(torch.from_numpy(rows.astype(np.int32)).cuda(), torch.from_numpy(scores).cuda(),
+                torch.from_numpy(cnt.astype(np.int32)).cuda(), 7, o_r, o_s, o_n)
+    torch.cuda.synchronize()
+    assert np.array_equal(o_r.cpu().numpy(), rows.astype(np.int32) + 7)
+    assert o_s.cpu().numpy().tobytes() == scores.tobytes()

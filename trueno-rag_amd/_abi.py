@@ -62,6 +62,10 @@ SIGNATURES = {
     "trag_store_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.c_uint64, _u32p]),
     "trag_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trag_pack_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                        C.c_void_p, C.c_void_p]),
+    "trag_merge_packed_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "trag_store_set_scan_mode": (C.c_int, [_H, C.c_uint32]),
     "trag_store_set_profiling": (C.c_int, [_H, C.c_int]),
     "trag_store_scan_time": (C.c_int, [_H, C.POINTER(C.c_double), _u32p]),

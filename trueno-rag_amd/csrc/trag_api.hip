@@ -591,6 +591,29 @@ trag_status trag_merge_topk_device(const uint32_t* d_rows, const float* d_scores
     return TRAG_OK;
 }
 
+trag_status trag_pack_topk_device(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_n,
+                                  uint32_t first_global_row, uint32_t n_queries, uint32_t k,
+                                  uint32_t* d_packed, void* hip_stream) {
+    if (!d_rows || !d_scores || !d_n || !d_packed) return fail(TRAG_INVALID_ARG, "null argument");
+    if (n_queries == 0) return TRAG_OK;
+    HIP_TRY(launch_pack_topk(d_rows, d_scores, d_n, first_global_row, n_queries, k, d_packed,
+                             (hipStream_t)hip_stream));
+    return TRAG_OK;
+}
+
+trag_status trag_merge_packed_device(const uint32_t* d_gathered, uint32_t n_lists,
+                                     uint32_t n_queries, uint32_t k, uint32_t* d_out_rows,
+                                     float* d_out_scores, uint32_t* d_out_n, void* hip_stream) {
+    if (!d_gathered || !d_out_rows || !d_out_scores || !d_out_n)
+        return fail(TRAG_INVALID_ARG, "null argument");
+    if ((uint64_t)n_lists * k > CAND_CAP)
+        return fail(TRAG_UNSUPPORTED, "n_lists * k exceeds " + std::to_string(CAND_CAP));
+    if (n_queries == 0) return TRAG_OK;
+    HIP_TRY(launch_merge_packed(d_gathered, n_lists, n_queries, k, d_out_rows, d_out_scores, d_out_n,
+                                (hipStream_t)hip_stream));
+    return TRAG_OK;
+}
+
 trag_status trag_store_last_stats(const trag_store* s, trag_search_stats* out) {
     if (!s || !out) return fail(TRAG_INVALID_ARG, "null argument");
     *out = s->stats;

@@ -95,6 +95,12 @@ hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint3
 hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_list_n,
                              uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t* d_out_rows,
                              float* d_out_scores, uint32_t* d_out_n, hipStream_t st);
+hipError_t launch_pack_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_n,
+                            uint32_t row0, uint32_t n_queries, uint32_t k, uint32_t* d_packed,
+                            hipStream_t st);
+hipError_t launch_merge_packed(const uint32_t* d_gathered, uint32_t n_lists, uint32_t n_queries,
+                               uint32_t k, uint32_t* d_out_rows, float* d_out_scores,
+                               uint32_t* d_out_n, hipStream_t st);
 hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
                               float* d_norm2_out, hipStream_t st);
 

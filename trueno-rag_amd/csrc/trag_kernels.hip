@@ -599,6 +599,75 @@ merge_topk_kernel(const uint32_t* __restrict__ rows, const float* __restrict__ s
     if (tid == 0) *out_n = n_out;
 }
 
+// Exchange record of one query: [k score bits | k global rows | count].
+__global__ void __launch_bounds__(256)
+pack_topk_kernel(const uint32_t* __restrict__ rows, const float* __restrict__ scores,
+                 const uint32_t* __restrict__ n, uint32_t row0, uint32_t n_queries, uint32_t k,
+                 uint32_t* __restrict__ packed) {
+    const uint32_t rec = 2u * k + 1u;
+    const uint32_t total = n_queries * rec;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const uint32_t q = e / rec, j = e - q * rec;
+        uint32_t v;
+        if (j < k) v = __float_as_uint(scores[(size_t)q * k + j]);
+        else if (j < 2u * k) v = rows[(size_t)q * k + (j - k)] + row0;
+        else v = n[q];
+        packed[e] = v;
+    }
+}
+
+// One workgroup per query: sort the gathered records of all shards.
+__global__ void __launch_bounds__(1024)
+merge_packed_kernel(const uint32_t* __restrict__ gathered, uint32_t n_lists, uint32_t n_queries,
+                    uint32_t k, uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
+                    uint32_t* __restrict__ out_n) {
+    __shared__ unsigned long long sk[CAND_CAP];
+    __shared__ uint32_t total_sh;
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    const uint32_t rec = 2u * k + 1u;
+    const uint32_t C = n_lists * k;
+    uint32_t P = 64;
+    while (P < C) P <<= 1;
+    if (tid == 0) total_sh = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < P; i += 1024u) {
+        unsigned long long v = 0ull;
+        if (i < C) {
+            const uint32_t l = i / k, j = i - l * k;
+            const uint32_t* r = gathered + ((size_t)l * n_queries + q) * rec;
+            const uint32_t cnt = min(r[2u * k], k);
+            if (j < cnt) {
+                v = rank_key(score_key(__uint_as_float(r[j])), r[k + j]);
+                mine += 1;
+            }
+        }
+        sk[i] = v;
+    }
+    if (mine) atomicAdd(&total_sh, mine);
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < P / 2; i += 1024u) {
+                const uint32_t pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = sk[pos], b = sk[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if (desc ? (a < b) : (a > b)) { sk[pos] = b; sk[pos + stride] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t total = total_sh;
+    const uint32_t n_out = k < total ? k : total;
+    for (uint32_t i = tid; i < n_out; i += 1024u) {
+        const unsigned long long v = sk[i];
+        out_rows[(size_t)q * k + i] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
+        out_scores[(size_t)q * k + i] = key_score((uint32_t)(v >> 32));
+    }
+    if (tid == 0) out_n[q] = n_out;
+}
+
 // ---------------------------------------------------------------------------
 // Synthetic corpus: counter-based components, then a sequential-sum L2
 // normalisation per row (two passes so that the stores are coalesced).
@@ -761,6 +830,23 @@ hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, cons
                              float* d_out_scores, uint32_t* d_out_n, hipStream_t st) {
     hipLaunchKernelGGL(merge_topk_kernel, dim3(1), dim3(1024), 0, st, d_rows, d_scores, d_list_n,
                        n_lists, k_in, k_out, d_out_rows, d_out_scores, d_out_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_n,
+                            uint32_t row0, uint32_t n_queries, uint32_t k, uint32_t* d_packed,
+                            hipStream_t st) {
+    const uint32_t grid = grid_for((uint64_t)n_queries * (2 * k + 1), 256, 1024);
+    hipLaunchKernelGGL(pack_topk_kernel, dim3(grid), dim3(256), 0, st, d_rows, d_scores, d_n, row0,
+                       n_queries, k, d_packed);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge_packed(const uint32_t* d_gathered, uint32_t n_lists, uint32_t n_queries,
+                               uint32_t k, uint32_t* d_out_rows, float* d_out_scores,
+                               uint32_t* d_out_n, hipStream_t st) {
+    hipLaunchKernelGGL(merge_packed_kernel, dim3(n_queries), dim3(1024), 0, st, d_gathered, n_lists,
+                       n_queries, k, d_out_rows, d_out_scores, d_out_n);
     return hipGetLastError();
 }
 
