@@ -115,9 +115,10 @@ trag_status trag_store_search_batch(trag_store *s, const float *queries, uint32_
  * store's device; work is enqueued on `hip_stream` (a hipStream_t, NULL = the
  * default stream) and the call returns without waiting. d_status[b] (optional,
  * may be NULL) receives 0 when query b's result is final; a non-zero value
- * means the streaming scan could not certify the ranking and the caller must
- * repeat that query (trag_store_search does this internally). With
- * TRAG_SCAN_EXACT the status is always 0. */
+ * (1 ranking not certified, 2 candidate overflow, 3 crowded score bin needs the
+ * multi-level select) means the fast path gave up and the caller must repeat
+ * that query with trag_store_search / _batch, which handle all three
+ * internally and remember the plan that worked for later calls. */
 trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint32_t n_queries,
                                      uint32_t dim, uint32_t k, uint32_t *d_out_rows,
                                      float *d_out_scores, uint32_t *d_out_n,

@@ -1,7 +1,9 @@
 // Host side of the C ABI declared in include/trag.h: the device-resident
 // vector store (row-major N x d fp32 in HBM, tombstone bitmap, per-handle
 // search scratch) and the search pipeline
-//     prep -> scan -> select (radix levels + compaction) -> final sort.
+//     scan -> select_final                       (one workgroup; the usual case)
+//     scan -> refine x2 -> compact -> final      (crowded score bins; chosen once a
+//                                                 query reported that it needs it)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -65,7 +67,10 @@ struct trag_store {
     uint32_t batch_q_cap = 0;
     // search scratch (one query in flight per handle)
     Scratch scratch{};
+    void* zero_block = nullptr;    // ctl | hist, zero between queries
+    size_t zero_bytes = 0;
     uint64_t keys_cap = 0;
+    bool full_select = false;      // learned: this corpus needs the multi-level select
     // staging for the host-pointer entry points
     float* d_q = nullptr;
     uint64_t d_q_cap = 0;          // floats
@@ -130,17 +135,23 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
 }
 
 trag_status ensure_scratch(trag_store* s) {
-    if (!s->scratch.ctl) {
-        HIP_TRY(hipMalloc(&s->scratch.ctl, sizeof(SearchCtl)));
-        HIP_TRY(hipMalloc(&s->scratch.hist, HIST_LEVELS * HIST_BINS * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&s->scratch.cand, CAND_CAP * sizeof(uint32_t)));
-    }
-    if (s->keys_cap < s->cap_rows) {
-        if (s->scratch.keys) (void)hipFree(s->scratch.keys);
-        if (s->scratch.tmax) (void)hipFree(s->scratch.tmax);
+    if (!s->scratch.cand) HIP_TRY(hipMalloc(&s->scratch.cand, CAND_CAP * sizeof(uint32_t)));
+    if (s->keys_cap < s->cap_rows || !s->zero_block) {
+        void* old[] = {s->scratch.keys, s->scratch.tmax, s->zero_block};
+        for (void* p : old)
+            if (p) (void)hipFree(p);
         s->scratch.keys = nullptr;
         s->scratch.tmax = nullptr;
+        s->zero_block = nullptr;
         s->keys_cap = 0;
+        const size_t ctl_bytes = 256;  // SearchCtl padded
+        static_assert(sizeof(SearchCtl) <= 256, "control block grew");
+        s->zero_bytes = ctl_bytes + HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
+        HIP_TRY(hipMalloc(&s->zero_block, s->zero_bytes));
+        HIP_TRY(hipMemset(s->zero_block, 0, s->zero_bytes));
+        s->scratch.ctl = reinterpret_cast<SearchCtl*>(s->zero_block);
+        s->scratch.hist = reinterpret_cast<uint32_t*>(static_cast<char*>(s->zero_block) + ctl_bytes);
+        if (!s->scratch.wmax) HIP_TRY(hipMalloc(&s->scratch.wmax, WMAX_CAP * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&s->scratch.keys, (size_t)s->cap_rows * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&s->scratch.tmax, ((size_t)s->cap_rows / 64 + 1) * sizeof(uint32_t)));
         s->keys_cap = s->cap_rows;
@@ -265,7 +276,6 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
     for (uint32_t b = 0; b < n_queries; ++b) {
         const float* q = d_queries + (size_t)b * s->cfg.dim;
-        HIP_TRY(launch_prep(q, a, s->scratch, need, k_eff, s->d_vmax_sq, st));
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (s->profiling && s->ev_used < 4096) {
             if (s->ev_used == s->ev_pool.size()) {
@@ -279,13 +289,22 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             s->ev_used += 1;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, st));
-        else HIP_TRY(launch_scan_exact(q, a, s->scratch, st));
+        if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, st));
+        else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
-        HIP_TRY(launch_select(a, s->scratch, st));
-        HIP_TRY(launch_final(q, a, s->scratch, rescore, live, d_out_rows + (size_t)b * k,
-                             d_out_scores + (size_t)b * k, d_out_n + b,
-                             d_status ? d_status + b : nullptr, st));
+        uint32_t* o_rows = d_out_rows + (size_t)b * k;
+        float* o_scores = d_out_scores + (size_t)b * k;
+        uint32_t* o_status = d_status ? d_status + b : nullptr;
+        if (!s->full_select) {
+            HIP_TRY(launch_select_final(q, a, s->scratch, rescore, live, o_rows, o_scores, d_out_n + b,
+                                        o_status, st));
+        } else {
+            HIP_TRY(launch_select(a, s->scratch, st));
+            HIP_TRY(launch_final(q, a, s->scratch, rescore, live, o_rows, o_scores, d_out_n + b, o_status, st));
+            // only the accumulators need clearing: ctl keeps the diagnostics until the next scan
+            HIP_TRY(hipMemsetAsync(s->scratch.hist, 0, s->zero_bytes - 256, st));
+            HIP_TRY(launch_reset_ctl(s->scratch, st));
+        }
     }
     s->stats.mode_used = mode;
     return TRAG_OK;
@@ -336,8 +355,7 @@ void trag_store_destroy(trag_store* s) {
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->batch.qpad, s->batch.ctls,
-                    s->batch.keys, s->batch.tmax, s->batch.cand, s->scratch.ctl, s->scratch.hist,
-                    s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->d_q, s->d_out_rows, s->d_out_scores,
+                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
                     s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -508,12 +526,21 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     s->stats.fallbacks = 0;
-    if (mode == TRAG_SCAN_STREAM || mode == TRAG_SCAN_MFMA) {
-        // Repeat, with the exact scan, every query whose ranking could not be certified.
-        for (uint32_t b = 0; b < n_queries; ++b) {
-            if (status[b] == ST_OK) continue;
-            s->stats.fallbacks += 1;
-            ts = enqueue_search(s, s->d_q + (size_t)b * dim, 1, k, TRAG_SCAN_EXACT,
+    // Repeat what the fast paths could not finish. A crowded coarse bin
+    // (ST_NEED_REFINE) needs the multi-level select, which is then remembered
+    // for later queries on this handle; an uncertified or overflowing
+    // streaming / matrix-core result is repeated with the exact scan.
+    for (uint32_t b = 0; b < n_queries; ++b) {
+        uint32_t cur_mode = mode;
+        for (int attempt = 0; attempt < 3 && status[b] != ST_OK; ++attempt) {
+            if (status[b] == ST_NEED_REFINE) {
+                s->full_select = true;
+                if (cur_mode == TRAG_SCAN_MFMA) cur_mode = TRAG_SCAN_EXACT;
+            } else {
+                s->stats.fallbacks += 1;
+                cur_mode = TRAG_SCAN_EXACT;
+            }
+            ts = enqueue_search(s, s->d_q + (size_t)b * dim, 1, k, cur_mode,
                                 s->d_out_rows + (size_t)b * k, s->d_out_scores + (size_t)b * k,
                                 s->d_out_n + b, s->d_out_status + b, st);
             if (ts != TRAG_OK) return ts;
@@ -522,10 +549,14 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
             HIP_TRY(hipMemcpyAsync(out_scores + (size_t)b * k, s->d_out_scores + (size_t)b * k,
                                    k * sizeof(float), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(out_n + b, s->d_out_n + b, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&status[b], s->d_out_status + b, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
-        s->stats.mode_used = mode;
+        if (status[b] != ST_OK)
+            return fail(TRAG_DEVICE_ERROR, "search could not be completed (status " +
+                                               std::to_string(status[b]) + ")");
     }
+    s->stats.mode_used = mode;
     if (mode == TRAG_SCAN_MFMA) {
         SearchCtl ctl;
         HIP_TRY(hipMemcpy(&ctl, s->batch.ctls, sizeof(ctl), hipMemcpyDeviceToHost));
@@ -535,7 +566,7 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
         SearchCtl ctl;
         HIP_TRY(hipMemcpy(&ctl, s->scratch.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
         s->stats.candidates = ctl.expect;
-        s->stats.refine_levels = ctl.resolved ? ctl.resolved : 3;
+        s->stats.refine_levels = ctl.levels;
     }
     return TRAG_OK;
 }

@@ -14,10 +14,13 @@ constexpr uint32_t CAND_CAP = 4096;
 // Extra candidates beyond k requested by the streaming mode, so that the
 // exactly re-scored top-k can be certified against everything left behind.
 constexpr uint32_t STREAM_SLACK = 32;
+// Most waves a scan grid may have (sizes the per-wave maxima).
+constexpr uint32_t WMAX_CAP = 16384;
 
 // Final status written per query.
 constexpr uint32_t ST_OK = 0;
 constexpr uint32_t ST_UNCERTIFIED = 1;  // streaming scan: margin check failed, repeat exactly
+constexpr uint32_t ST_NEED_REFINE = 3;  // one-workgroup select: coarse bin too crowded, use the full select
 
 // Per-query control block in device memory. Written by prep_kernel and by
 // block 0 of each select stage; read by the stages after it on the same stream.
@@ -37,13 +40,17 @@ struct SearchCtl {
     uint32_t expect;     // candidates the final stage must find
     uint32_t cand_count; // atomic append cursor
     uint32_t status;
-    uint32_t pad;
+    uint32_t levels;     // radix levels the last select needed (diagnostics)
+    uint32_t n_waves;    // waves of the scan grid: tile t was scanned by wave t % n_waves
 };
 
 // Device scratch of one in-flight query.
 struct Scratch {
+    // ctl and hist live in one allocation ("zero block"): they are what a
+    // scan accumulates into and must be zero when a query starts.
     SearchCtl* ctl;      // 1
     uint32_t* hist;      // HIST_LEVELS * HIST_BINS
+    uint32_t* wmax;      // WMAX_CAP: largest key each scan wave saw (not an accumulator)
     uint32_t* cand;      // CAND_CAP row indices
     uint32_t* keys;      // capacity rows, ordered 32-bit keys (0 = removed row)
     uint32_t* tmax;      // capacity rows / 64: largest key of each 64-row tile
@@ -72,12 +79,16 @@ struct ScanArgs {
 };
 
 // ---- kernel launchers (trag_kernels.hip) ----
-hipError_t launch_prep(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                       uint32_t k, const float* d_vmax_sq, hipStream_t st);
-hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s, hipStream_t st);
-hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, hipStream_t st);
+hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                             uint32_t k, const float* d_vmax_sq, hipStream_t st);
+hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                              uint32_t k, const float* d_vmax_sq, hipStream_t st);
+hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
+                               uint32_t live, uint32_t* d_out_rows, float* d_out_scores,
+                               uint32_t* d_out_n, uint32_t* d_status, hipStream_t st);
 bool stream_supports_dim(uint32_t dim);
 hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st);
+hipError_t launch_reset_ctl(const Scratch& s, hipStream_t st);
 hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
                         uint32_t live, uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
                         uint32_t* d_status, hipStream_t st);

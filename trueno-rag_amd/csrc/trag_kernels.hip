@@ -7,59 +7,9 @@
 // where written as __builtin_fmaf.
 #include "trag_device.h"
 #include "trag_internal.h"
+#include "trag_scan_common.h"
 
 namespace trag {
-
-// ---------------------------------------------------------------------------
-// prep: zero the histograms, initialise the control block, compute ||q||.
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-prep_kernel(const float* __restrict__ q, uint32_t d, SearchCtl* __restrict__ ctl,
-            uint32_t* __restrict__ hist, uint32_t need, uint32_t k,
-            const float* __restrict__ vmax_sq) {
-    __shared__ __attribute__((aligned(16))) float qs[4096];
-    const int tid = threadIdx.x;
-    for (uint32_t i = tid; i < HIST_LEVELS * HIST_BINS; i += 256) hist[i] = 0u;
-    // sum q*q in the reference's order (src/index.rs:442): one thread, left to right.
-    float acc = 0.0f;
-    for (uint32_t base = 0; base < d; base += 4096) {
-        const uint32_t len = min(4096u, d - base);
-        __syncthreads();
-        for (uint32_t i = tid; i < len; i += 256) qs[i] = q[base + i];
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t i = 0;
-            for (; i + 4 <= len; i += 4) {  // wide LDS reads; the adds stay strictly in order
-                const v4f x = *reinterpret_cast<const v4f*>(&qs[i]);
-                float p0 = x.x * x.x, p1 = x.y * x.y, p2 = x.z * x.z, p3 = x.w * x.w;
-                acc = acc + p0;
-                acc = acc + p1;
-                acc = acc + p2;
-                acc = acc + p3;
-            }
-            for (; i < len; ++i) {
-                float p = qs[i] * qs[i];
-                acc = acc + p;
-            }
-        }
-    }
-    if (tid == 0) {
-        ctl->na_sq = acc;
-        ctl->na = sqrtf(acc);
-        ctl->vmax_sq = vmax_sq ? *vmax_sq : 0.0f;
-        ctl->need = need;
-        ctl->k = k;
-        ctl->resolved = 0;
-        ctl->b1 = ctl->above1 = ctl->b2 = ctl->above2 = 0;
-        ctl->t_key = 0;
-        ctl->cut_ties = 0;
-        ctl->tie_quota = 0;
-        ctl->above3 = 0;
-        ctl->expect = 0;
-        ctl->cand_count = 0;
-        ctl->status = ST_OK;
-    }
-}
 
 // ---------------------------------------------------------------------------
 // Score arithmetic, reference order. METRIC: 0 cosine, 1 euclidean, 2 dot.
@@ -115,26 +65,27 @@ template <int METRIC>
 __global__ void __launch_bounds__(256)
 scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
                      const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
-                     const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
-                     uint32_t* __restrict__ tmax, uint32_t* __restrict__ hist) {
+                     uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
+                     SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
+                     uint32_t* __restrict__ tmax, uint32_t* __restrict__ wmax,
+                     uint32_t* __restrict__ hist) {
     __shared__ __attribute__((aligned(16))) float tiles[4][64 * EX_STRIDE];
     __shared__ uint32_t lhist[HIST_BINS];
+    __shared__ float na_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
-    __syncthreads();
 
     float* tile = tiles[wid];
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t d4 = d >> 2;
     const uint32_t n_chunks = (d + EX_CW - 1) / EX_CW;
-    const float na = ctl->na;
     const int lrow = lane >> 3;   // row of a load within its group of 8
     const int lcol = lane & 7;    // float4 column within the chunk
 
     uint32_t t = blockIdx.x * 4u + wid;
-    if (t < n_tiles) {
-        v4f pre[8];
+    v4f pre[8];
+    {
         // issue the loads of chunk c of tile tt
         auto issue = [&](uint32_t tt, uint32_t c) {
             const uint32_t col4 = min(c * 8u + (uint32_t)lcol, d4 - 1u);
@@ -145,7 +96,21 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
                 pre[i] = __builtin_nontemporal_load(p);
             }
         };
-        issue(t, 0);
+        if (t < n_tiles) issue(t, 0);
+        // ||q|| while the first loads are in flight: one wave per workgroup runs
+        // the sequential sum (cosine needs it in every workgroup; for the other
+        // metrics only the copy published for the final stage is used)
+        if (wid == 0 && (METRIC == 0 || blockIdx.x == 0)) {
+            const float nsq = query_norm_sq_wave(q, d, lane);
+            if (lane == 0) {
+                na_sh = sqrtf(nsq);
+                if (blockIdx.x == 0) publish_ctl(ctl, nsq, need, k, vmax_sq, gridDim.x * 4u);
+            }
+        }
+        __syncthreads();  // also covers the histogram zeroing above
+        const float na = METRIC == 0 ? na_sh : 0.0f;
+        uint32_t wave_best = 0u;  // largest key over all tiles of this wave
+        const uint32_t wave_id = blockIdx.x * 4u + wid;
         while (t < n_tiles) {
             float acc0 = 0.0f, acc1 = 0.0f;
             for (uint32_t c = 0; c < n_chunks; ++c) {
@@ -192,9 +157,13 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
                 keys[row] = key;
             }
             const uint32_t tm = wave_max_u32(key);
-            if (lane == 0) tmax[t] = tm;
+            if (lane == 0) {
+                tmax[t] = tm;
+            }
+            wave_best = tm > wave_best ? tm : wave_best;
             t += n_waves;
         }
+        if (lane == 0) wmax[wave_id] = wave_best;
     }
     __syncthreads();
     for (int i = tid; i < (int)HIST_BINS; i += 256) {
@@ -209,13 +178,18 @@ template <int METRIC>
 __global__ void __launch_bounds__(256)
 scan_exact_any_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
                       const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
-                      const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
-                      uint32_t* __restrict__ tmax, uint32_t* __restrict__ hist) {
+                      uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
+                      SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
+                      uint32_t* __restrict__ tmax, uint32_t* __restrict__ wmax,
+                      uint32_t* __restrict__ hist) {
     __shared__ uint32_t lhist[HIST_BINS];
     const int tid = threadIdx.x;
     for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
     __syncthreads();
-    const float na = ctl->na;
+    const float nsq = query_norm_sq_wave(q, d, tid & 63);
+    const float na = sqrtf(nsq);
+    if (blockIdx.x == 0 && tid == 0) publish_ctl(ctl, nsq, need, k, vmax_sq, gridDim.x * 4u);
+    uint32_t wave_best = 0u;
     // each wave covers one aligned 64-row tile per iteration
     for (uint32_t base = blockIdx.x * 256u; base < n_rows; base += gridDim.x * 256u) {
         const uint32_t row = base + tid;
@@ -231,7 +205,9 @@ scan_exact_any_kernel(const float* __restrict__ corpus, const float* __restrict_
         const uint32_t tm = wave_max_u32(key);
         const uint32_t tile = (base + (tid & ~63u)) >> 6;
         if ((tid & 63) == 0 && (base + (tid & ~63u)) < n_rows) tmax[tile] = tm;
+        wave_best = tm > wave_best ? tm : wave_best;
     }
+    if ((tid & 63) == 0) wmax[blockIdx.x * 4u + (tid >> 6)] = wave_best;
     __syncthreads();
     for (int i = tid; i < (int)HIST_BINS; i += 256) {
         const uint32_t h = lhist[i];
@@ -244,16 +220,19 @@ scan_exact_any_kernel(const float* __restrict__ corpus, const float* __restrict_
 // and at most CAND_CAP rows lie at or above it.
 // ---------------------------------------------------------------------------
 
-// Called by all 256 threads of a workgroup. hist has HIST_BINS bins. Returns
-// the highest bin b whose suffix count (bins >= b) reaches `need`, and the
-// count strictly above it. sh: 8 words of LDS.
+// Called by all NT threads of a workgroup (NT = 256 or 1024). hist has
+// HIST_BINS bins. Returns the highest bin b whose suffix count (bins >= b)
+// reaches `need`, and the count strictly above it. sh: NT/64 + 2 words of LDS.
+template <int NT>
 __device__ void find_bin(const uint32_t* __restrict__ hist, uint32_t need, uint32_t& bin,
                          uint32_t& above, uint32_t* sh) {
+    constexpr int BPT = (int)HIST_BINS / NT;  // bins per thread
+    constexpr int NW = NT / 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int top = (int)HIST_BINS - 1 - 8 * t;  // thread t owns bins top, top-1, ..., top-7
-    uint32_t h[8], sum = 0;
+    const int top = (int)HIST_BINS - 1 - BPT * t;  // thread t owns bins top, top-1, ...
+    uint32_t h[BPT], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { h[i] = hist[top - i]; sum += h[i]; }
+    for (int i = 0; i < BPT; ++i) { h[i] = hist[top - i]; sum += h[i]; }
     uint32_t incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -261,25 +240,27 @@ __device__ void find_bin(const uint32_t* __restrict__ hist, uint32_t need, uint3
         if (lane >= o) incl += v;
     }
     if (lane == 63) sh[w] = incl;
-    if (t == 0) { sh[4] = 0; sh[5] = 0; }
+    if (t == 0) { sh[NW] = 0; sh[NW + 1] = 0; }
     __syncthreads();
-    uint32_t base = 0;
-    for (int i = 0; i < w; ++i) base += sh[i];
-    const uint32_t total = sh[0] + sh[1] + sh[2] + sh[3];
+    uint32_t base = 0, total = 0;
+    for (int i = 0; i < NW; ++i) {
+        if (i < w) base += sh[i];
+        total += sh[i];
+    }
     incl += base;
     const uint32_t excl = incl - sum;
     if (need > total) need = total;
     if (need > 0 && excl < need && need <= incl) {
         uint32_t cum = excl;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (cum + h[i] >= need) { sh[4] = (uint32_t)(top - i); sh[5] = cum; break; }
+        for (int i = 0; i < BPT; ++i) {
+            if (cum + h[i] >= need) { sh[NW] = (uint32_t)(top - i); sh[NW + 1] = cum; break; }
             cum += h[i];
         }
     }
     __syncthreads();
-    bin = sh[4];
-    above = sh[5];
+    bin = sh[NW];
+    above = sh[NW + 1];
     __syncthreads();
 }
 
@@ -302,7 +283,7 @@ refine_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __r
     uint32_t prefix, shift_match, shift_bin, mask_bin;
     if (LEVEL == 2) {
         uint32_t b1, above1;
-        find_bin(hist, need, b1, above1, sh);
+        find_bin<256>(hist, need, b1, above1, sh);
         const uint32_t inbin = hist[b1];
         if (above1 + inbin <= CAND_CAP) {
             if (blockIdx.x == 0 && tid == 0) {
@@ -317,7 +298,7 @@ refine_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, SearchCtl* __r
     } else {
         const uint32_t b1 = ctl->b1, above1 = ctl->above1;
         uint32_t b2, a2;
-        find_bin(hist + HIST_BINS, need - above1, b2, a2, sh);
+        find_bin<256>(hist + HIST_BINS, need - above1, b2, a2, sh);
         const uint32_t inbin = hist[HIST_BINS + b2];
         const uint32_t above2 = above1 + a2;
         if (above2 + inbin <= CAND_CAP) {
@@ -371,7 +352,7 @@ compact_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ t
         const uint32_t need = ctl->need;
         const uint32_t b1 = ctl->b1, b2 = ctl->b2, above2 = ctl->above2;
         uint32_t b3, a3;
-        find_bin(hist + 2 * HIST_BINS, need - above2, b3, a3, sh);
+        find_bin<256>(hist + 2 * HIST_BINS, need - above2, b3, a3, sh);
         const uint32_t inbin = hist[2 * HIST_BINS + b3];
         above3 = above2 + a3;
         t_key = (b1 << 21) | (b2 << 10) | b3;
@@ -458,6 +439,27 @@ __device__ float exact_score_row(const float* __restrict__ v, const float* __res
     return finish_score<METRIC>(acc0, acc1, na);
 }
 
+
+// Streaming / batched modes: every row left behind has an approximate score
+// <= t (the select threshold) and approximate and exact scores differ by at
+// most eps, so the exact top-k is final when its last member clears t + eps.
+template <int METRIC>
+__device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float na, uint32_t t_key,
+                            float ek) {
+    uint32_t status = ST_OK;
+    const float u = 5.9604645e-08f;  // 2^-24
+    float eps = (2.0f * (float)d + 64.0f) * u;
+    const float vmax = sqrtf(ctl->vmax_sq);
+    if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
+    if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
+    // the bound assumes ||q||^2 is a normal number well inside the f32 range
+    const float nsq = ctl->na_sq;
+    if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f))) status = ST_UNCERTIFIED;
+    const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
+    if (!(ek > t + eps) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
+    return status;
+}
+
 template <int METRIC, bool RESCORE>
 __global__ void __launch_bounds__(1024)
 final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows,
@@ -525,25 +527,135 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
     if (tid == 0) {
         *out_n = n_out;
         uint32_t status = ST_OK;
-        if (RESCORE && C < live && n_out > 0) {
-            // Every row left behind has an approximate score <= t (the select
-            // threshold) and approximate and exact scores differ by at most eps,
-            // so the exact top-k is certified when its last member clears t + eps.
-            const float u = 5.9604645e-08f;  // 2^-24
-            float eps = (2.0f * (float)d + 64.0f) * u;
-            const float vmax = sqrtf(ctl->vmax_sq);
-            if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
-            if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
-            // the bound assumes ||q||^2 is a normal number well inside the f32 range
-            const float nsq = ctl->na_sq;
-            if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f))) status = ST_UNCERTIFIED;
-            const uint32_t t_key = ctl->t_key;
-            const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
-            const float ek = key_score((uint32_t)(sk[n_out - 1] >> 32));
-            if (!(ek > t + eps) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
-        }
+        if (RESCORE && C < live && n_out > 0)
+            status = certify<METRIC>(ctl, d, na, ctl->t_key, key_score((uint32_t)(sk[n_out - 1] >> 32)));
         if (overflow) status = ST_OVERFLOW;
         ctl->status = status;
+        if (out_status) *out_status = status;
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// select_final: the common case in ONE workgroup. The scan's histogram gives
+// the coarse bin that holds the need-th best key; when the rows at or above
+// that bin fit the sort they are collected through the two levels of tile
+// maxima (supertile = 64 tiles = 4096 rows), (optionally re-scored,) sorted and
+// written out; the workgroup then zeroes what the next query's scan
+// accumulates into. When the bin is too crowded (clustered scores, big tie
+// groups) the status ST_NEED_REFINE asks the host for the multi-level pipeline.
+// ---------------------------------------------------------------------------
+template <int METRIC, bool RESCORE>
+__global__ void __launch_bounds__(1024)
+select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows,
+                    uint32_t d, uint32_t live, SearchCtl* __restrict__ ctl,
+                    uint32_t* __restrict__ hist, const uint32_t* __restrict__ keys,
+                    const uint32_t* __restrict__ tmax, uint32_t* __restrict__ wmax,
+                    uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
+                    uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_status) {
+    __shared__ unsigned long long sk[CAND_CAP];
+    __shared__ uint32_t hit[CAND_CAP];
+    __shared__ uint32_t sh[24];
+    __shared__ uint32_t n_hit_sh, n_cand_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t need = ctl->need, k = ctl->k;
+    const float na = ctl->na;
+    const uint32_t n_tiles = (n_rows + 63u) >> 6;
+    const uint32_t n_waves = ctl->n_waves;
+    uint32_t b1, above1;
+    find_bin<1024>(hist, need, b1, above1, sh);
+    const uint32_t expect = above1 + hist[b1];
+    uint32_t status = ST_OK, n_out = 0, C = 0;
+    if (expect > CAND_CAP) {
+        status = ST_NEED_REFINE;
+    } else {
+        const uint32_t t_key = b1 << 21;
+        const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
+        if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; }
+        __syncthreads();
+        // scan waves whose best key reaches the threshold ...
+        for (uint32_t w0 = 0; w0 < n_waves; w0 += 1024u) {
+            const uint32_t w = w0 + tid;
+            if (w < n_waves && w < n_tiles && wmax[w] >= t_min) {
+                const uint32_t pos = atomicAdd(&n_hit_sh, 1u);
+                if (pos < CAND_CAP) hit[pos] = w;
+            }
+        }
+        __syncthreads();
+        const uint32_t nh = n_hit_sh < CAND_CAP ? n_hit_sh : CAND_CAP;
+        // ... then their tiles (w, w + n_waves, ...), then the rows of the tiles that pass
+        for (uint32_t h = wid; h < nh; h += 16u) {
+            const uint32_t w = hit[h];
+            for (uint32_t tb = 0; w + tb * n_waves < n_tiles; tb += 64u) {
+                const uint32_t tile = w + (tb + lane) * n_waves;
+                const uint32_t tm = tile < n_tiles ? tmax[tile] : 0u;
+                unsigned long long hits = __ballot(tm >= t_min);
+                while (hits) {
+                    const uint32_t j = (uint32_t)__ffsll((long long)hits) - 1u;
+                    hits &= hits - 1ull;
+                    const uint32_t i = (w + (tb + j) * n_waves) * 64u + lane;
+                    const uint32_t key = i < n_rows ? keys[i] : 0u;
+                    const bool acc = key >= t_min;
+                    const unsigned long long m = __ballot(acc);
+                    if (m) {
+                        uint32_t pos0 = 0;
+                        if (lane == 0) pos0 = atomicAdd(&n_cand_sh, (uint32_t)__popcll(m));
+                        pos0 = __shfl(pos0, 0);
+                        if (acc) {
+                            const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            if (pos < CAND_CAP) sk[pos] = RESCORE ? (unsigned long long)i : rank_key(key, i);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
+        uint32_t P = 64;
+        while (P < C) P <<= 1;
+        for (uint32_t i = tid; i < P; i += 1024u) {
+            unsigned long long v = 0ull;
+            if (i < C) {
+                v = sk[i];
+                if (RESCORE) {
+                    const uint32_t row = (uint32_t)v;
+                    v = rank_key(score_key(exact_score_row<METRIC>(corpus + (size_t)row * d, q, d, na)), row);
+                }
+            }
+            sk[i] = v;
+        }
+        for (uint32_t size = 2; size <= P; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (uint32_t i = tid; i < P / 2; i += 1024u) {
+                    const uint32_t pos = 2 * i - (i & (stride - 1));
+                    const unsigned long long a = sk[pos], b = sk[pos + stride];
+                    const bool desc = (pos & size) == 0;
+                    if (desc ? (a < b) : (a > b)) { sk[pos] = b; sk[pos + stride] = a; }
+                }
+            }
+        }
+        __syncthreads();
+        n_out = k < C ? k : C;
+        for (uint32_t i = tid; i < n_out; i += 1024u) {
+            const unsigned long long v = sk[i];
+            out_rows[i] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
+            float sc = key_score((uint32_t)(v >> 32));
+            if (METRIC == 1 && sc == 0.0f) sc = -0.0f;  // -(sqrt(0)) in the reference
+            out_scores[i] = sc;
+        }
+        if (RESCORE && C < live && n_out > 0)
+            status = certify<METRIC>(ctl, d, na, t_key, key_score((uint32_t)(sk[n_out - 1] >> 32)));
+    }
+    // leave the accumulators clean for the next query's scan
+    for (uint32_t i = tid; i < HIST_BINS; i += 1024u) hist[i] = 0u;
+    if (tid == 0) {
+        *out_n = n_out;
+        ctl->expect = C;
+        ctl->t_key = b1 << 21;
+        ctl->levels = 1;
+        ctl->status = status;
+        ctl->levels = ctl->resolved ? ctl->resolved : 3;
         if (out_status) *out_status = status;
     }
 }
@@ -735,34 +847,27 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
     return (uint32_t)g;
 }
 
-hipError_t launch_prep(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                       uint32_t k, const float* d_vmax_sq, hipStream_t st) {
-    hipLaunchKernelGGL(prep_kernel, dim3(1), dim3(256), 0, st, d_q, a.dim, s.ctl, s.hist, need, k,
-                       d_vmax_sq);
-    return hipGetLastError();
-}
-
 template <int METRIC>
-static void scan_exact_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s,
-                                hipStream_t st) {
+static void scan_exact_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                                uint32_t k, const float* d_vmax_sq, hipStream_t st) {
     if ((a.dim & 3u) == 0u) {
         const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
         const uint32_t grid = grid_for(n_tiles, 4, 256 * 3);
         hipLaunchKernelGGL(scan_exact_v4_kernel<METRIC>, dim3(grid), dim3(256), 0, st, a.corpus,
-                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.tmax, s.hist);
+                           d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys, s.tmax, s.wmax, s.hist);
     } else {
         const uint32_t grid = grid_for(a.n_rows, 256, 256 * 8);
         hipLaunchKernelGGL(scan_exact_any_kernel<METRIC>, dim3(grid), dim3(256), 0, st, a.corpus,
-                           d_q, a.dead, a.n_rows, a.dim, s.ctl, s.keys, s.tmax, s.hist);
+                           d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys, s.tmax, s.wmax, s.hist);
     }
 }
 
-hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s,
-                             hipStream_t st) {
+hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                             uint32_t k, const float* d_vmax_sq, hipStream_t st) {
     switch (a.metric) {
-    case TRAG_COSINE: scan_exact_dispatch<0>(d_q, a, s, st); break;
-    case TRAG_EUCLIDEAN: scan_exact_dispatch<1>(d_q, a, s, st); break;
-    default: scan_exact_dispatch<2>(d_q, a, s, st); break;
+    case TRAG_COSINE: scan_exact_dispatch<0>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case TRAG_EUCLIDEAN: scan_exact_dispatch<1>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    default: scan_exact_dispatch<2>(d_q, a, s, need, k, d_vmax_sq, st); break;
     }
     return hipGetLastError();
 }
@@ -809,6 +914,52 @@ hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, b
         break;
     default:
         final_dispatch<2>(d_q, a, s, rescore, live, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        break;
+    }
+    return hipGetLastError();
+}
+
+// After the multi-kernel select: clear the fields of the control block that a
+// query accumulates into (the histograms are cleared with a memset).
+__global__ void reset_ctl_kernel(SearchCtl* ctl) {
+    ctl->resolved = 0;
+    ctl->cand_count = 0;
+    ctl->cut_ties = 0;
+    ctl->tie_quota = 0;
+    ctl->b1 = ctl->above1 = ctl->b2 = ctl->above2 = ctl->above3 = 0;
+}
+
+hipError_t launch_reset_ctl(const Scratch& s, hipStream_t st) {
+    hipLaunchKernelGGL(reset_ctl_kernel, dim3(1), dim3(1), 0, st, s.ctl);
+    return hipGetLastError();
+}
+
+template <int METRIC>
+static void select_final_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
+                                  uint32_t live, uint32_t* d_out_rows, float* d_out_scores,
+                                  uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
+    if (rescore)
+        hipLaunchKernelGGL((select_final_kernel<METRIC, true>), dim3(1), dim3(1024), 0, st, a.corpus,
+                           d_q, a.n_rows, a.dim, live, s.ctl, s.hist, s.keys, s.tmax, s.wmax,
+                           d_out_rows, d_out_scores, d_out_n, d_status);
+    else
+        hipLaunchKernelGGL((select_final_kernel<METRIC, false>), dim3(1), dim3(1024), 0, st, a.corpus,
+                           d_q, a.n_rows, a.dim, live, s.ctl, s.hist, s.keys, s.tmax, s.wmax,
+                           d_out_rows, d_out_scores, d_out_n, d_status);
+}
+
+hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
+                               uint32_t live, uint32_t* d_out_rows, float* d_out_scores,
+                               uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
+    switch (a.metric) {
+    case TRAG_COSINE:
+        select_final_dispatch<0>(d_q, a, s, rescore, live, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        break;
+    case TRAG_EUCLIDEAN:
+        select_final_dispatch<1>(d_q, a, s, rescore, live, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        break;
+    default:
+        select_final_dispatch<2>(d_q, a, s, rescore, live, d_out_rows, d_out_scores, d_out_n, d_status, st);
         break;
     }
     return hipGetLastError();

@@ -11,6 +11,7 @@
 // result against a rigorous bound on |approximate - exact|.
 #include "trag_device.h"
 #include "trag_internal.h"
+#include "trag_scan_common.h"
 
 namespace trag {
 
@@ -58,9 +59,10 @@ __device__ __forceinline__ float finish_fast(float a0, float a1, float na) {
 template <int METRIC, int G, int NV, int U>
 __global__ void __launch_bounds__(256)
 scan_stream_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
-                   const uint32_t* __restrict__ dead, uint32_t n_rows,
-                   const SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
-                   uint32_t* __restrict__ tmax, uint32_t* __restrict__ hist) {
+                   const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t need, uint32_t k,
+                   const float* __restrict__ vmax_sq, SearchCtl* __restrict__ ctl,
+                   uint32_t* __restrict__ keys, uint32_t* __restrict__ tmax,
+                   uint32_t* __restrict__ wmax, uint32_t* __restrict__ hist) {
     constexpr int RPW = 64 / G;   // rows per wave iteration
     constexpr int ITERS = G;      // iterations per 64-row tile
     constexpr int D4 = G * NV;    // float4 per row
@@ -68,19 +70,31 @@ scan_stream_kernel(const float* __restrict__ corpus, const float* __restrict__ q
     static_assert(ITERS % U == 0, "unroll must divide the tile");
     __shared__ v4f qs[D4];
     __shared__ uint32_t lhist[HIST_BINS];
+    __shared__ float na_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
     for (int i = tid; i < D4; i += 256) qs[i] = reinterpret_cast<const v4f*>(q)[i];
+    // ||q|| with the reference's sequential sum, by one wave per workgroup:
+    // needed for cosine scores, and published once for the final stage's
+    // re-score and error bound
+    if (wid == 0 && (METRIC == 0 || blockIdx.x == 0)) {
+        const float nsq = query_norm_sq_wave(q, D, lane);
+        if (lane == 0) {
+            na_sh = sqrtf(nsq);
+            if (blockIdx.x == 0) publish_ctl(ctl, nsq, need, k, vmax_sq, gridDim.x * 4u);
+        }
+    }
     __syncthreads();
     const int gl = lane % G, sub = lane / G;
     v4f qr[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) qr[j] = qs[j * G + gl];
-    const float na = ctl->na;
+    const float na = METRIC == 0 ? na_sh : 0.0f;
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t last = n_rows - 1u;
 
+    uint32_t wave_best = 0u;  // largest key over all tiles of this wave
     for (uint32_t t = blockIdx.x * 4u + wid; t < n_tiles; t += n_waves) {
         const uint32_t row0 = t * 64u;
         float mine = 0.0f;
@@ -120,7 +134,9 @@ scan_stream_kernel(const float* __restrict__ corpus, const float* __restrict__ q
         }
         const uint32_t tm = wave_max_u32(key);
         if (lane == 0) tmax[t] = tm;
+        wave_best = tm > wave_best ? tm : wave_best;
     }
+    if (lane == 0) wmax[blockIdx.x * 4u + wid] = wave_best;
     __syncthreads();
     for (int i = tid; i < (int)HIST_BINS; i += 256) {
         const uint32_t h = lhist[i];
@@ -141,7 +157,8 @@ bool stream_supports_dim(uint32_t d) {
 }
 
 template <int METRIC, int G, int NV, int U>
-static void launch_one(const float* d_q, const ScanArgs& a, const Scratch& s, hipStream_t st) {
+static void launch_one(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                       uint32_t k, const float* d_vmax_sq, hipStream_t st) {
     const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
     uint32_t grid = (n_tiles + 3u) / 4u;
     // one resident wave set: workgroups per CU from the occupancy query, times the CU count
@@ -154,36 +171,39 @@ static void launch_one(const float* d_q, const ScanArgs& a, const Scratch& s, hi
         if (hipGetDevice(&dev) == hipSuccess)
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         cap = (uint32_t)per_cu * (uint32_t)cus;
+        if (cap * 4u > WMAX_CAP) cap = WMAX_CAP / 4u;
     }
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL((scan_stream_kernel<METRIC, G, NV, U>), dim3(grid), dim3(256), 0, st,
-                       a.corpus, d_q, a.dead, a.n_rows, s.ctl, s.keys, s.tmax, s.hist);
+                       a.corpus, d_q, a.dead, a.n_rows, need, k, d_vmax_sq, s.ctl, s.keys, s.tmax, s.wmax,
+                       s.hist);
 }
 
 template <int METRIC>
-static void launch_metric(const float* d_q, const ScanArgs& a, const Scratch& s, hipStream_t st) {
+static void launch_metric(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                          uint32_t k, const float* d_vmax_sq, hipStream_t st) {
     switch (a.dim) {
-    case 128: launch_one<METRIC, 32, 1, 8>(d_q, a, s, st); break;
-    case 384: launch_one<METRIC, 32, 3, 4>(d_q, a, s, st); break;
-    case 256: launch_one<METRIC, 64, 1, 8>(d_q, a, s, st); break;
-    case 512: launch_one<METRIC, 64, 2, 4>(d_q, a, s, st); break;
-    case 768: launch_one<METRIC, 64, 3, 4>(d_q, a, s, st); break;
-    case 1024: launch_one<METRIC, 64, 4, 4>(d_q, a, s, st); break;
-    case 1536: launch_one<METRIC, 64, 6, 2>(d_q, a, s, st); break;
-    case 2048: launch_one<METRIC, 64, 8, 2>(d_q, a, s, st); break;
-    case 3072: launch_one<METRIC, 64, 12, 1>(d_q, a, s, st); break;
-    case 4096: launch_one<METRIC, 64, 16, 1>(d_q, a, s, st); break;
+    case 128: launch_one<METRIC, 32, 1, 8>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 384: launch_one<METRIC, 32, 3, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 256: launch_one<METRIC, 64, 1, 8>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 512: launch_one<METRIC, 64, 2, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 768: launch_one<METRIC, 64, 3, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 1024: launch_one<METRIC, 64, 4, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 1536: launch_one<METRIC, 64, 6, 2>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 2048: launch_one<METRIC, 64, 8, 2>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 3072: launch_one<METRIC, 64, 12, 1>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case 4096: launch_one<METRIC, 64, 16, 1>(d_q, a, s, need, k, d_vmax_sq, st); break;
     default: break;
     }
 }
 
-hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s,
-                              hipStream_t st) {
+hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+                              uint32_t k, const float* d_vmax_sq, hipStream_t st) {
     if (!stream_supports_dim(a.dim)) return hipErrorInvalidValue;
     switch (a.metric) {
-    case TRAG_COSINE: launch_metric<0>(d_q, a, s, st); break;
-    case TRAG_EUCLIDEAN: launch_metric<1>(d_q, a, s, st); break;
-    default: launch_metric<2>(d_q, a, s, st); break;
+    case TRAG_COSINE: launch_metric<0>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case TRAG_EUCLIDEAN: launch_metric<1>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    default: launch_metric<2>(d_q, a, s, need, k, d_vmax_sq, st); break;
     }
     return hipGetLastError();
 }
