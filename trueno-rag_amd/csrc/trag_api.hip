@@ -148,7 +148,10 @@ trag_status ensure_scratch(trag_store* s) {
         static_assert(sizeof(SearchCtl) <= 256, "control block grew");
         s->zero_bytes = ctl_bytes + HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
         HIP_TRY(hipMalloc(&s->zero_block, s->zero_bytes));
-        HIP_TRY(hipMemset(s->zero_block, 0, s->zero_bytes));
+        // stream-ordered clear, finished before any stream can use the block (a plain
+        // hipMemset on the null stream is not ordered against non-blocking streams)
+        HIP_TRY(hipMemsetAsync(s->zero_block, 0, s->zero_bytes, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
         s->scratch.ctl = reinterpret_cast<SearchCtl*>(s->zero_block);
         s->scratch.hist = reinterpret_cast<uint32_t*>(static_cast<char*>(s->zero_block) + ctl_bytes);
         if (!s->scratch.wmax) HIP_TRY(hipMalloc(&s->scratch.wmax, WMAX_CAP * sizeof(uint32_t)));
@@ -289,15 +292,16 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             s->ev_used += 1;
             HIP_TRY(hipEventRecord(e0, st));
         }
-        if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, st));
-        else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, st));
+        uint32_t n_waves = 0;
+        if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
+        else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
         uint32_t* o_rows = d_out_rows + (size_t)b * k;
         float* o_scores = d_out_scores + (size_t)b * k;
         uint32_t* o_status = d_status ? d_status + b : nullptr;
         if (!s->full_select) {
-            HIP_TRY(launch_select_final(q, a, s->scratch, rescore, live, o_rows, o_scores, d_out_n + b,
-                                        o_status, st));
+            HIP_TRY(launch_select_final(q, a, s->scratch, rescore, live, need, k_eff, n_waves, o_rows,
+                                        o_scores, d_out_n + b, o_status, st));
         } else {
             HIP_TRY(launch_select(a, s->scratch, st));
             HIP_TRY(launch_final(q, a, s->scratch, rescore, live, o_rows, o_scores, d_out_n + b, o_status, st));
@@ -338,7 +342,8 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
     e = hipMalloc(&s->d_vmax_sq, sizeof(float));
-    if (e == hipSuccess) e = hipMemset(s->d_vmax_sq, 0, sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_vmax_sq, 0, sizeof(float), s->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) { trag_store_destroy(s); return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
     if (cfg->reserve_rows) {
         trag_status ts = grow_rows(s, cfg->reserve_rows);

@@ -79,13 +79,15 @@ struct ScanArgs {
 };
 
 // ---- kernel launchers (trag_kernels.hip) ----
+// the scans report the number of waves of their grid (tile t is scanned by wave t % n_waves)
 hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                             uint32_t k, const float* d_vmax_sq, hipStream_t st);
+                             uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st);
 hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                              uint32_t k, const float* d_vmax_sq, hipStream_t st);
+                              uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st);
 hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
-                               uint32_t live, uint32_t* d_out_rows, float* d_out_scores,
-                               uint32_t* d_out_n, uint32_t* d_status, hipStream_t st);
+                               uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
+                               uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
+                               uint32_t* d_status, hipStream_t st);
 bool stream_supports_dim(uint32_t dim);
 hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st);
 hipError_t launch_reset_ctl(const Scratch& s, hipStream_t st);

@@ -157,7 +157,7 @@ bool stream_supports_dim(uint32_t d) {
 }
 
 template <int METRIC, int G, int NV, int U>
-static void launch_one(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+static uint32_t launch_one(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
                        uint32_t k, const float* d_vmax_sq, hipStream_t st) {
     const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
     uint32_t grid = (n_tiles + 3u) / 4u;
@@ -177,33 +177,34 @@ static void launch_one(const float* d_q, const ScanArgs& a, const Scratch& s, ui
     hipLaunchKernelGGL((scan_stream_kernel<METRIC, G, NV, U>), dim3(grid), dim3(256), 0, st,
                        a.corpus, d_q, a.dead, a.n_rows, need, k, d_vmax_sq, s.ctl, s.keys, s.tmax, s.wmax,
                        s.hist);
+    return grid * 4u;
 }
 
 template <int METRIC>
-static void launch_metric(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
+static uint32_t launch_metric(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
                           uint32_t k, const float* d_vmax_sq, hipStream_t st) {
     switch (a.dim) {
-    case 128: launch_one<METRIC, 32, 1, 8>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 384: launch_one<METRIC, 32, 3, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 256: launch_one<METRIC, 64, 1, 8>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 512: launch_one<METRIC, 64, 2, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 768: launch_one<METRIC, 64, 3, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 1024: launch_one<METRIC, 64, 4, 4>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 1536: launch_one<METRIC, 64, 6, 2>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 2048: launch_one<METRIC, 64, 8, 2>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 3072: launch_one<METRIC, 64, 12, 1>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case 4096: launch_one<METRIC, 64, 16, 1>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    default: break;
+    case 128: return launch_one<METRIC, 32, 1, 8>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 384: return launch_one<METRIC, 32, 3, 4>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 256: return launch_one<METRIC, 64, 1, 8>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 512: return launch_one<METRIC, 64, 2, 4>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 768: return launch_one<METRIC, 64, 3, 4>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 1024: return launch_one<METRIC, 64, 4, 4>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 1536: return launch_one<METRIC, 64, 6, 2>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 2048: return launch_one<METRIC, 64, 8, 2>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 3072: return launch_one<METRIC, 64, 12, 1>(d_q, a, s, need, k, d_vmax_sq, st);
+    case 4096: return launch_one<METRIC, 64, 16, 1>(d_q, a, s, need, k, d_vmax_sq, st);
+    default: return 0;
     }
 }
 
 hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                              uint32_t k, const float* d_vmax_sq, hipStream_t st) {
+                              uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st) {
     if (!stream_supports_dim(a.dim)) return hipErrorInvalidValue;
     switch (a.metric) {
-    case TRAG_COSINE: launch_metric<0>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case TRAG_EUCLIDEAN: launch_metric<1>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    default: launch_metric<2>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case TRAG_COSINE: *n_waves = launch_metric<0>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case TRAG_EUCLIDEAN: *n_waves = launch_metric<1>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    default: *n_waves = launch_metric<2>(d_q, a, s, need, k, d_vmax_sq, st); break;
     }
     return hipGetLastError();
 }
