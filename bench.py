@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 matrix cores")
     ap.add_argument("--batch", type=int, default=1, help="queries per step (>= 8: matrix-core path)")
+    ap.add_argument("--hybrid", action="store_true",
+                    help="hybrid step: dense top-50 + a synthetic sparse top-50 list -> RRF(60) -> top-k on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     return ap.parse_args()
@@ -94,7 +96,33 @@ def main():
         m_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
         m_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
 
+    hybrid_out = []
+    if args.hybrid:
+        assert world == 1 and B == 1, "--hybrid is a single-GPU, single-query step"
+        cand = 50  # HybridRetrieverConfig::candidates_per_source, src/retrieve.rs:94
+        rng = np.random.default_rng(seed + 7)
+        fusion = pkg.FusionStrategy.RRF(60.0)
+        h_rows = torch.zeros((n_q, cand), dtype=torch.int32, device="cuda")
+        h_scores = torch.zeros((n_q, cand), dtype=torch.float32, device="cuda")
+
+    def hybrid_step(i):
+        """src/retrieve.rs:175-220 with the BM25 list replaced by a seeded list that shares
+        ~30% of its ids with the dense list (the sparse index itself is CPU work in the reference)."""
+        store.search_device(Q.data_ptr() + i * d * esz, 1, cand, h_rows.data_ptr() + i * cand * esz,
+                            h_scores.data_ptr() + i * cand * esz, out_n.data_ptr() + i * esz,
+                            status.data_ptr() + i * esz, sptr)
+        rows = h_rows[i].cpu().numpy()          # synchronises: the fusion runs on the host
+        scores = h_scores[i].cpu().numpy()
+        dense = list(zip(rows.tolist(), scores.tolist()))
+        shared = rng.choice(rows, size=15, replace=False)
+        fresh = rng.integers(0, n_local, size=35)
+        sparse_ids = rng.permutation(np.concatenate([shared, fresh]))
+        sparse = [(int(r), 10.0 - 0.1 * j) for j, r in enumerate(sparse_ids)]
+        hybrid_out.append(fusion.fuse(dense, sparse)[:k])
+
     def step(s):
+        if args.hybrid:
+            return hybrid_step(s)
         i = s * B
         store.search_device(Q.data_ptr() + i * d * esz, B, k, out_rows.data_ptr() + i * k * esz,
                             out_scores.data_ptr() + i * k * esz, out_n.data_ptr() + i * esz,
@@ -127,6 +155,9 @@ def main():
 
     # ---- parity at full size (outside the timed region) ----
     uncertified = int((status[args.warmup * B:] != 0).sum().item())
+    if args.hybrid:
+        out_rows, out_scores = h_rows, h_scores
+        k = cand
     final_rows = (m_rows if ex is not None else out_rows)[-1].cpu().numpy().astype(np.uint32)
     final_scores = (m_scores if ex is not None else out_scores)[-1].cpu().numpy()
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
@@ -159,7 +190,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, cosine top-{k}",
+            "config": {"workload": (f"{n_total}x{d} fp32 corpus in HBM, hybrid step: dense cosine top-50 + synthetic "
+                                    f"sparse top-50 -> RRF(60) on the host -> top-{args.k}") if args.hybrid else
+                       f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, cosine top-{k}",
                        "rows": n_total, "dim": d, "k": k, "batch": B, "metric": "cosine",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
                        "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma"}[args.mode]},

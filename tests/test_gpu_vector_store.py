@@ -477,3 +477,21 @@ def test_two_shards_on_one_gpu_merge_to_global_topk(trag, oracle):
     torch.cuda.synchronize()
     assert np.array_equal(o_r.cpu().numpy(), rows.astype(np.int32) + 7)
     assert o_s.cpu().numpy().tobytes() == scores.tobytes()
+
+
+def test_config1_plumbing_shape(trag, oracle):
+    """The reference's CPU-runnable case: a 10k-vector 384-d index, one query, top-10
+    (MockEmbedder(384) rows are unit-norm pseudo-random vectors; their exact values
+    are not pinned by the reference, so seeded unit rows stand in)."""
+    n, d = 10_000, 384
+    store = trag.VectorStore.with_dimension(d)
+    corpus = oracle.synth_rows(1001, 0, n, d)
+    chunks = [trag.Chunk(content=f"chunk {i}", embedding=corpus[i]) for i in range(n)]
+    store.insert_batch(chunks)
+    q = oracle.synth_rows(1101, 0, 1, d)[0]
+    res = store.search(q, 10)
+    er, es = oracle.search(corpus, q, 10, 0)
+    assert [chunks.index(store.get(cid)) for cid, _ in res] == er.tolist()
+    assert np.array([s for _, s in res], dtype=np.float32).tobytes() == es.tobytes()
+    fr, fs = oracle.search_faithful(corpus, q, 10, 0)   # the reference-shaped loop agrees
+    assert fr.tolist() == er.tolist() and fs.tobytes() == es.tobytes()
