@@ -17,8 +17,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BT_M = 128;        // queries per workgroup tile
 constexpr int BT_N = 128;        // corpus rows per workgroup tile
-constexpr int BT_K = 32;         // k-step staged through LDS
-constexpr int BT_LD = BT_K + 4;  // padded LDS row stride (floats): conflict-free b128 reads
+constexpr int BT_KMIN = 32;      // dimensions must be a multiple of this
 
 // prep for a block of queries: one workgroup per query computes ||q|| in the
 // reference's order and resets that query's control block.
@@ -82,15 +81,20 @@ prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict
 // reads its 16 operands as four contiguous ds_read_b128.
 // METRIC: 0 cosine, 2 dot product.
 // ---------------------------------------------------------------------------
-template <int METRIC>
+template <int METRIC, int BT_K /* k-step staged through LDS */>
 __global__ void __launch_bounds__(256)
 gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpad,
                  const float* __restrict__ norm2, const uint32_t* __restrict__ dead,
                  uint32_t n_rows, uint32_t d, uint32_t n_queries, uint32_t q_tiles,
                  const SearchCtl* __restrict__ ctls, uint32_t* __restrict__ keys,
                  size_t keys_stride, uint32_t* __restrict__ tmax, size_t tmax_stride) {
-    __shared__ __attribute__((aligned(16))) float As[BT_M * BT_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BT_N * BT_LD];
+    constexpr int BT_LD = BT_K + 4;  // padded LDS row stride (floats): conflict-free b128 reads
+    constexpr int NLD = BT_K / 8;    // 16-byte loads per thread per operand tile (256 threads)
+    constexpr int CPR = BT_K / 4;    // float4 columns per tile row
+    constexpr int RPP = 256 / CPR;   // rows covered by one pass of the 256 threads
+    constexpr int KH = BT_K / 2;     // k-values per lane half
+    __shared__ __attribute__((aligned(16))) float As_[1][BT_M * BT_LD];
+    __shared__ __attribute__((aligned(16))) float Bs_[1][BT_N * BT_LD];
     __shared__ float na_s[BT_M];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -108,19 +112,19 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
 
     if (tid < BT_M) na_s[tid] = (q0 + tid < n_queries) ? ctls[q0 + tid].na : 0.0f;
 
-    // staging map: thread -> (row = tid/8 + 32*i, float4 column = tid%8)
-    const int srow = tid >> 3, scol = tid & 7;
-    const float* aptr[4];
-    const float* bptr[4];
+    // staging map: thread -> (row = tid/CPR + RPP*i, float4 column = tid%CPR)
+    const int srow = tid / CPR, scol = tid % CPR;
+    const float* aptr[NLD];
+    const float* bptr[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        aptr[i] = Qpad + (size_t)(q0 + srow + 32 * i) * d + scol * 4;
-        const uint32_t r = min(n0 + (uint32_t)(srow + 32 * i), n_rows - 1u);
+    for (int i = 0; i < NLD; ++i) {
+        aptr[i] = Qpad + (size_t)(q0 + srow + RPP * i) * d + scol * 4;
+        const uint32_t r = min(n0 + (uint32_t)(srow + RPP * i), n_rows - 1u);
         bptr[i] = corpus + (size_t)r * d + scol * 4;
     }
-    v4f ra[4], rb[4];
+    v4f ra[NLD], rb[NLD];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NLD; ++i) {
         ra[i] = *reinterpret_cast<const v4f*>(aptr[i]);
         rb[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i]));
     }
@@ -133,47 +137,61 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-    const int frow = lane & 31, fk = (lane >> 5) * 16;
+    const int frow = lane & 31, fk = (lane >> 5) * KH;
     const uint32_t nk = d / BT_K;
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            *reinterpret_cast<v4f*>(&As_[buf][(srow + RPP * i) * BT_LD + scol * 4]) = ra[i];
+            *reinterpret_cast<v4f*>(&Bs_[buf][(srow + RPP * i) * BT_LD + scol * 4]) = rb[i];
+        }
+    };
+    auto prefetch = [&](uint32_t kt) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            ra[i] = *reinterpret_cast<const v4f*>(aptr[i] + (size_t)kt * BT_K);
+            rb[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i] + (size_t)kt * BT_K));
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* As = As_[buf];
+        const float* Bs = Bs_[buf];
+#pragma unroll
+        for (int kk = 0; kk < KH / 16; ++kk) {  // 16 MFMA k-slots per pass
+            v4f fa[2][4], fb[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fa[m][j] = *reinterpret_cast<const v4f*>(
+                        &As[(wm * 64 + m * 32 + frow) * BT_LD + fk + kk * 16 + j * 4]);
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fb[n][j] = *reinterpret_cast<const v4f*>(
+                        &Bs[(wn * 64 + n * 32 + frow) * BT_LD + fk + kk * 16 + j * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][j][e], fb[n][j][e],
+                                                                             acc[m][n], 0, 0, 0);
+        }
+    };
+    // Measured alternatives on MI355X (1M x 768, 256 queries): this loop 107-111 TFLOP/s;
+    // two LDS images with one barrier per step 103; 64-wide k-steps 102; s_setprio
+    // around the MFMA block 106. The chip holds ~2.03 GHz under this load.
     for (uint32_t kt = 0; kt < nk; ++kt) {
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<v4f*>(&As[(srow + 32 * i) * BT_LD + scol * 4]) = ra[i];
-            *reinterpret_cast<v4f*>(&Bs[(srow + 32 * i) * BT_LD + scol * 4]) = rb[i];
-        }
+        stage(0);
         __syncthreads();
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const v4f*>(aptr[i] + (size_t)(kt + 1) * BT_K);
-                rb[i] = __builtin_nontemporal_load(
-                    reinterpret_cast<const v4f*>(bptr[i] + (size_t)(kt + 1) * BT_K));
-            }
-        }
-        v4f fa[2][4], fb[2][4];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                fa[m][j] = *reinterpret_cast<const v4f*>(
-                    &As[(wm * 64 + m * 32 + frow) * BT_LD + fk + j * 4]);
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                fb[n][j] = *reinterpret_cast<const v4f*>(
-                    &Bs[(wn * 64 + n * 32 + frow) * BT_LD + fk + j * 4]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][j][e], fb[n][j][e],
-                                                                         acc[m][n], 0, 0, 0);
+        if (kt + 1 < nk) prefetch(kt + 1);
+        compute(0);
     }
 
     // ---- epilogue: scores -> ordered keys, per-(query, 64-row tile) maxima ----
@@ -327,7 +345,7 @@ pad_queries_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t pad
 }
 
 bool batch_supports(uint32_t dim, uint32_t metric) {
-    return (dim % BT_K) == 0 && (metric == TRAG_COSINE || metric == TRAG_DOT_PRODUCT);
+    return (dim % BT_KMIN) == 0 && (metric == TRAG_COSINE || metric == TRAG_DOT_PRODUCT);
 }
 
 hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a,
@@ -343,13 +361,13 @@ hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArg
     const uint32_t groups = (n_tiles128 + 7) / 8;  // corpus tiles in groups of 8 (one per XCD slot)
     const uint32_t grid = groups * q_tiles * 8;
     if (a.metric == TRAG_COSINE)
-        hipLaunchKernelGGL(gemm_scan_kernel<0>, dim3(grid), dim3(256), 0, st, a.corpus, s.qpad, d_norm2,
-                           a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys, s.keys_stride,
-                           s.tmax, s.tmax_stride);
+        hipLaunchKernelGGL((gemm_scan_kernel<0, 32>), dim3(grid), dim3(256), 0, st, a.corpus, s.qpad,
+                           d_norm2, a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys,
+                           s.keys_stride, s.tmax, s.tmax_stride);
     else
-        hipLaunchKernelGGL(gemm_scan_kernel<2>, dim3(grid), dim3(256), 0, st, a.corpus, s.qpad, d_norm2,
-                           a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys, s.keys_stride,
-                           s.tmax, s.tmax_stride);
+        hipLaunchKernelGGL((gemm_scan_kernel<2, 32>), dim3(grid), dim3(256), 0, st, a.corpus, s.qpad,
+                           d_norm2, a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys,
+                           s.keys_stride, s.tmax, s.tmax_stride);
     const uint32_t n_tiles64 = (a.n_rows + 63) / 64;
     hipLaunchKernelGGL(tau_select_kernel, dim3(n_queries), dim3(256), 0, st, s.tmax, s.tmax_stride,
                        n_tiles64, s.ctls);
