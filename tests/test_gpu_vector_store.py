@@ -495,3 +495,27 @@ def test_config1_plumbing_shape(trag, oracle):
     assert np.array([s for _, s in res], dtype=np.float32).tobytes() == es.tobytes()
     fr, fs = oracle.search_faithful(corpus, q, 10, 0)   # the reference-shaped loop agrees
     assert fr.tolist() == er.tolist() and fs.tobytes() == es.tobytes()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_large_k_returns_every_row_sorted(trag, oracle, metric):
+    """k far beyond the one-workgroup sort (and k > len): the reference never
+    errors (src/index.rs:409), it returns min(k, len) rows in order."""
+    n, d = 30_000, 128
+    rng = np.random.default_rng(21)
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    corpus[100] = corpus[20_000]
+    store = make_store(trag, d, metric)
+    store.insert_rows(corpus)
+    store.remove_row(7)
+    dead = np.zeros(n, dtype=np.uint8)
+    dead[7] = 1
+    q = corpus[100].copy()
+    for k in (5000, 29_999, 50_000):
+        rows, scores = store.search_rows(q, k)
+        er, es = oracle.search(corpus, q, k, metric, dead=dead)
+        assert len(rows) == min(k, n - 1)
+        assert_same_ranking(rows, scores, er, es, f"large k={k} metric={metric}")
+    rows, scores = store.search_rows(q, 10)          # the usual path still works afterwards
+    er, es = oracle.search(corpus, q, 10, metric, dead=dead)
+    assert_same_ranking(rows, scores, er, es, "after large k")

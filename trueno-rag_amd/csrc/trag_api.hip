@@ -71,6 +71,8 @@ struct trag_store {
     size_t zero_bytes = 0;
     uint64_t keys_cap = 0;
     bool full_select = false;      // learned: this corpus needs the multi-level select
+    unsigned long long* d_sort = nullptr;  // large-k path: rank keys of every row, padded to 2^m
+    unsigned long long sort_cap = 0;
     // staging for the host-pointer entry points
     float* d_q = nullptr;
     uint64_t d_q_cap = 0;          // floats
@@ -238,6 +240,32 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     if (ts != TRAG_OK) return ts;
     const uint32_t live = (uint32_t)s->n_live;
     const uint32_t k_eff = std::min<uint32_t>(k, live);
+    if (k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP) {
+        // More results than the one-workgroup sort holds: exact scan, then a
+        // global sort of every row's rank key (rare; the reference's callers ask
+        // for at most 100).
+        unsigned long long padded = 64;
+        while (padded < s->n_rows) padded <<= 1;
+        if (s->sort_cap < padded) {
+            if (s->d_sort) (void)hipFree(s->d_sort);
+            s->d_sort = nullptr;
+            s->sort_cap = 0;
+            HIP_TRY(hipMalloc(&s->d_sort, padded * sizeof(unsigned long long)));
+            s->sort_cap = padded;
+        }
+        ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+        for (uint32_t b = 0; b < n_queries; ++b) {
+            const float* q = d_queries + (size_t)b * s->cfg.dim;
+            uint32_t n_waves = 0;
+            HIP_TRY(launch_scan_exact(q, a, s->scratch, k_eff, k_eff, s->d_vmax_sq, &n_waves, st));
+            HIP_TRY(launch_full_sort(a, s->scratch, s->d_sort, padded, k_eff, d_out_rows + (size_t)b * k,
+                                     d_out_scores + (size_t)b * k, d_out_n + b,
+                                     d_status ? d_status + b : nullptr, st));
+            HIP_TRY(hipMemsetAsync(s->scratch.hist, 0, s->zero_bytes - 256, st));
+        }
+        s->stats.mode_used = TRAG_SCAN_EXACT;
+        return TRAG_OK;
+    }
     if (mode == TRAG_SCAN_MFMA) {
         const uint32_t need_b = (uint32_t)std::min<uint64_t>((uint64_t)k_eff + STREAM_SLACK, live);
         if (need_b > CAND_CAP) return fail(TRAG_UNSUPPORTED, "k exceeds the single-workgroup final sort");
@@ -360,7 +388,7 @@ void trag_store_destroy(trag_store* s) {
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->batch.qpad, s->batch.ctls,
-                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
+                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->d_sort, s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
                     s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -91,6 +91,10 @@ hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratc
 bool stream_supports_dim(uint32_t dim);
 hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st);
 hipError_t launch_reset_ctl(const Scratch& s, hipStream_t st);
+hipError_t launch_full_sort(const ScanArgs& a, const Scratch& s, unsigned long long* d_sort,
+                            unsigned long long padded, uint32_t n_out, uint32_t* d_out_rows,
+                            float* d_out_scores, uint32_t* d_out_n, uint32_t* d_status,
+                            hipStream_t st);
 hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
                         uint32_t live, uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
                         uint32_t* d_status, hipStream_t st);

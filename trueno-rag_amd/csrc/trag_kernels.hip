@@ -971,6 +971,75 @@ hipError_t launch_final(const float* d_q, const ScanArgs& a, const Scratch& s, b
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Large k (more results than the one-workgroup sort holds): sort every row.
+// rank keys of all rows -> global bitonic network, one launch per step.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rank_keys_kernel(const uint32_t* __restrict__ keys, uint32_t n_rows, unsigned long long padded,
+                 unsigned long long* __restrict__ out) {
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < padded;
+         i += (unsigned long long)gridDim.x * 256ull) {
+        unsigned long long v = 0ull;
+        if (i < n_rows) {
+            const uint32_t key = keys[i];
+            if (key) v = rank_key(key, (uint32_t)i);  // removed rows sort last as 0
+        }
+        out[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bitonic_step_kernel(unsigned long long* __restrict__ a, unsigned long long padded,
+                    unsigned long long size, unsigned long long stride) {
+    const unsigned long long half = padded >> 1;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < half;
+         i += (unsigned long long)gridDim.x * 256ull) {
+        const unsigned long long pos = 2ull * i - (i & (stride - 1ull));
+        const unsigned long long x = a[pos], y = a[pos + stride];
+        const bool desc = (pos & size) == 0ull;
+        if (desc ? (x < y) : (x > y)) { a[pos] = y; a[pos + stride] = x; }
+    }
+}
+
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+emit_sorted_kernel(const unsigned long long* __restrict__ sorted, uint32_t n_out,
+                   uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
+                   uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_status) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_out; i += gridDim.x * 256u) {
+        const unsigned long long v = sorted[i];
+        out_rows[i] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
+        float sc = key_score((uint32_t)(v >> 32));
+        if (METRIC == 1 && sc == 0.0f) sc = -0.0f;
+        out_scores[i] = sc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *out_n = n_out;
+        if (out_status) *out_status = ST_OK;
+    }
+}
+
+hipError_t launch_full_sort(const ScanArgs& a, const Scratch& s, unsigned long long* d_sort,
+                            unsigned long long padded, uint32_t n_out, uint32_t* d_out_rows,
+                            float* d_out_scores, uint32_t* d_out_n, uint32_t* d_status,
+                            hipStream_t st) {
+    const uint32_t grid = grid_for(padded, 256 * 4, 256 * 8);
+    hipLaunchKernelGGL(rank_keys_kernel, dim3(grid), dim3(256), 0, st, s.keys, a.n_rows, padded, d_sort);
+    for (unsigned long long size = 2; size <= padded; size <<= 1)
+        for (unsigned long long stride = size >> 1; stride > 0; stride >>= 1)
+            hipLaunchKernelGGL(bitonic_step_kernel, dim3(grid), dim3(256), 0, st, d_sort, padded, size,
+                               stride);
+    const uint32_t egrid = grid_for(n_out, 256, 1024);
+    if (a.metric == TRAG_EUCLIDEAN)
+        hipLaunchKernelGGL(emit_sorted_kernel<1>, dim3(egrid), dim3(256), 0, st, d_sort, n_out,
+                           d_out_rows, d_out_scores, d_out_n, d_status);
+    else
+        hipLaunchKernelGGL(emit_sorted_kernel<0>, dim3(egrid), dim3(256), 0, st, d_sort, n_out,
+                           d_out_rows, d_out_scores, d_out_n, d_status);
+    return hipGetLastError();
+}
+
 // After the multi-kernel select: clear the fields of the control block that a
 // query accumulates into (the histograms are cleared with a memset).
 __global__ void reset_ctl_kernel(SearchCtl* ctl) {
