@@ -1,0 +1,114 @@
+// The reference's VectorStore / fusion / retriever unit tests (src/index.rs:667-867,
+// src/fusion.rs:267-325, src/retrieve.rs:464-531) driven through the C++ host mirror.
+// Needs a GPU. Exit code 0 = all passed.
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "trueno_rag.hpp"
+
+using namespace trueno_rag;
+
+static int failures = 0;
+#define EXPECT(cond)                                                                    \
+    do {                                                                                \
+        if (!(cond)) { std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); ++failures; } \
+    } while (0)
+
+static Chunk chunk_with(const std::string& text, std::vector<float> e) { return Chunk(text).with_embedding(std::move(e)); }
+
+struct StubEmbedder {
+    std::vector<float> embed_query(const std::string& q) const {
+        if (q.empty()) throw QueryError("empty query");
+        std::vector<float> v(3, 0.0f);
+        v[(q[0] - 'a') % 3] = 1.0f;
+        return v;
+    }
+};
+struct StubSparse {
+    std::vector<ChunkId> ids;
+    void add(const Chunk& c) { ids.push_back(c.id); }
+    std::vector<std::pair<ChunkId, float>> search(const std::string&, size_t k) const {
+        std::vector<std::pair<ChunkId, float>> out;
+        for (size_t i = 0; i < ids.size() && i < k; ++i) out.emplace_back(ids[ids.size() - 1 - i], 5.0f - (float)i);
+        return out;
+    }
+};
+
+int main() {
+    {   // test_vector_store_new / insert / remove
+        VectorStore store = VectorStore::with_dimension(384);
+        EXPECT(store.config().dimension == 384 && store.is_empty());
+        VectorStore s3 = VectorStore::with_dimension(3);
+        Chunk c = chunk_with("test", {1.0f, 0.0f, 0.0f});
+        ChunkId id = c.id;
+        s3.insert(c);
+        EXPECT(s3.len() == 1 && !s3.is_empty() && s3.get(id) != nullptr);
+        EXPECT(s3.remove(id).has_value() && s3.len() == 0 && s3.get(id) == nullptr);
+        EXPECT(!s3.remove(ChunkId::random()).has_value());
+    }
+    {   // errors: src/index.rs:704-726, 793-797
+        VectorStore s = VectorStore::with_dimension(3);
+        try { s.insert(Chunk("no embedding")); EXPECT(false); } catch (const InvalidConfig&) {}
+        try { s.insert(chunk_with("x", {1.0f, 0.0f})); EXPECT(false); }
+        catch (const DimensionMismatch& e) { EXPECT(e.expected == 3 && e.actual == 2); }
+        try { s.search({1.0f, 0.0f}, 10); EXPECT(false); }
+        catch (const DimensionMismatch& e) { EXPECT(e.expected == 3 && e.actual == 2); }
+    }
+    {   // test_vector_store_search_cosine, :742-772
+        VectorStore s = VectorStore::with_dimension(3);
+        Chunk c1 = chunk_with("north", {1.0f, 0.0f, 0.0f}), c2 = chunk_with("east", {0.0f, 1.0f, 0.0f});
+        Chunk c3 = chunk_with("diagonal", {0.70710677f, 0.70710677f, 0.0f});
+        ChunkId id1 = c1.id, id3 = c3.id;
+        s.insert(c1); s.insert(c2); s.insert(c3);
+        auto r = s.search({0.9f, 0.1f, 0.0f}, 10);
+        EXPECT(r.size() == 3 && r[0].first == id1 && r[1].first == id3);
+    }
+    {   // test_vector_store_search_top_k, :775-790
+        VectorStore s = VectorStore::with_dimension(3);
+        for (int i = 0; i < 10; ++i) s.insert(chunk_with("chunk", {(float)i, 0.0f, 0.0f}));
+        EXPECT(s.search({9.0f, 0.0f, 0.0f}, 3).size() == 3);
+    }
+    {   // euclidean / dot product, :822-867
+        VectorStoreConfig cfg; cfg.dimension = 2; cfg.metric = DistanceMetric::Euclidean;
+        VectorStore s(cfg);
+        Chunk a = chunk_with("origin", {0.0f, 0.0f}), b = chunk_with("near", {1.0f, 0.0f}), c = chunk_with("far", {10.0f, 0.0f});
+        ChunkId ia = a.id, ib = b.id;
+        s.insert(a); s.insert(b); s.insert(c);
+        auto r = s.search({0.0f, 0.0f}, 10);
+        EXPECT(r[0].first == ia && r[1].first == ib);
+        cfg.metric = DistanceMetric::DotProduct;
+        VectorStore d(cfg);
+        Chunk sm = chunk_with("small", {1.0f, 0.0f}), lg = chunk_with("large", {10.0f, 0.0f});
+        ChunkId il = lg.id;
+        d.insert(sm); d.insert(lg);
+        EXPECT(d.search({1.0f, 0.0f}, 10)[0].first == il);
+    }
+    {   // RRF: src/fusion.rs:297-325
+        FusionStrategy f;
+        ChunkId a = ChunkId::from_u128(1), b = ChunkId::from_u128(2), c = ChunkId::from_u128(3);
+        auto r = f.fuse({{a, 0.9f}, {b, 0.8f}}, {{a, 0.9f}, {c, 0.8f}});
+        EXPECT(r.size() == 3 && r[0].first == a);
+        auto one = f.fuse({{a, 1.0f}}, {{a, 1.0f}});
+        EXPECT(std::fabs(one[0].second - 2.0f / 61.0f) < 1e-3f);
+        EXPECT(f.fuse({}, {}).empty());
+    }
+    {   // hybrid + dense retrievers: shape checks as src/retrieve.rs:464-531
+        HybridRetriever<StubEmbedder, StubSparse> hr(VectorStore::with_dimension(3), StubSparse{}, StubEmbedder{});
+        std::vector<Chunk> cs = {chunk_with("alpha", {1, 0, 0}), chunk_with("beta", {0, 1, 0}), chunk_with("gamma", {0, 0, 1})};
+        ChunkId first = cs[0].id;
+        hr.index_batch(cs);
+        EXPECT(hr.len() == 3);
+        auto res = hr.retrieve("a", 2);
+        EXPECT(res.size() == 2 && res[0].fused_score.has_value());
+        EXPECT(res[0].best_score() >= res[1].best_score());
+        auto dres = hr.retrieve_dense("a", 1);
+        EXPECT(dres.size() == 1 && dres[0].chunk.id == first && dres[0].dense_score.has_value());
+        DenseRetriever<StubEmbedder> dr(VectorStore::with_dimension(3), StubEmbedder{});
+        dr.index(chunk_with("beta", {0, 1, 0}));
+        EXPECT(dr.retrieve("b", 5).size() == 1);
+    }
+    std::printf(failures ? "%d failure(s)\n" : "host mirror: all checks passed\n", failures);
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,291 @@
+// C++ host mirror of the part of trueno-rag's API that sits on the dense
+// retrieval path, over the C ABI of include/trag.h. Names, argument meaning
+// and error behaviour follow the reference (paths relative to its tree):
+//   VectorStore, VectorStoreConfig, DistanceMetric     src/index.rs:282-437
+//   FusionStrategy                                      src/fusion.rs:9-63
+//   RetrievalResult, HybridRetrieverConfig,
+//   HybridRetriever, DenseRetriever                     src/retrieve.rs:13-297
+// Result<T, Error> becomes exceptions derived from trueno_rag::Error.
+// Header-only; link with -ltrag. There is no CPU fallback behind it.
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "trag.h"
+
+namespace trueno_rag {
+
+// ---- errors (src/error.rs:9-64) ----
+struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+struct DimensionMismatch : Error {
+    size_t expected, actual;
+    DimensionMismatch(size_t e, size_t a)
+        : Error("dimension mismatch: expected " + std::to_string(e) + ", got " + std::to_string(a)),
+          expected(e), actual(a) {}
+};
+struct InvalidConfig : Error { using Error::Error; };
+struct VectorStoreError : Error { using Error::Error; };  // Error::VectorStore(String)
+struct QueryError : Error { using Error::Error; };        // Error::Query(String)
+
+inline void check(int status, size_t expected = 0, size_t actual = 0) {
+    if (status == TRAG_OK) return;
+    if (status == TRAG_DIM_MISMATCH) throw DimensionMismatch(expected, actual);
+    if (status == TRAG_INVALID_CONFIG) throw InvalidConfig(trag_last_error());
+    throw VectorStoreError(trag_last_error());
+}
+
+// ---- ids and chunks (src/chunk.rs:7-99) ----
+struct ChunkId {
+    uint64_t hi = 0, lo = 0;
+    static ChunkId random() {  // Uuid::new_v4
+        static thread_local std::mt19937_64 g{std::random_device{}()};
+        return ChunkId{g(), g()};
+    }
+    static ChunkId from_u128(uint64_t lo) { return ChunkId{0, lo}; }
+    bool operator==(const ChunkId& o) const { return hi == o.hi && lo == o.lo; }
+    bool operator!=(const ChunkId& o) const { return !(*this == o); }
+};
+struct ChunkIdHash {
+    size_t operator()(const ChunkId& c) const { return std::hash<uint64_t>()(c.hi * 0x9E3779B97F4A7C15ull ^ c.lo); }
+};
+
+struct Chunk {
+    ChunkId id = ChunkId::random();
+    std::string content;
+    std::optional<std::vector<float>> embedding;
+    Chunk() = default;
+    explicit Chunk(std::string text) : content(std::move(text)) {}
+    Chunk with_embedding(std::vector<float> e) && { embedding = std::move(e); return std::move(*this); }
+};
+
+// ---- VectorStore ----
+enum class DistanceMetric : uint32_t { Cosine = 0, Euclidean = 1, DotProduct = 2 };
+
+struct VectorStoreConfig {
+    size_t dimension = 384;
+    DistanceMetric metric = DistanceMetric::Cosine;
+    size_t hnsw_m = 16, hnsw_ef_construction = 100, hnsw_ef_search = 50;  // never read, as in the reference
+    int device = -1;          // not in the reference: HIP device of this store
+};
+
+class VectorStore {
+  public:
+    explicit VectorStore(VectorStoreConfig config) : config_(config) {
+        trag_config c{(uint32_t)config.dimension, (uint32_t)config.metric, config.device, TRAG_SCAN_AUTO, 0};
+        check(trag_store_create(&c, &h_));
+    }
+    static VectorStore with_dimension(size_t dimension) {
+        VectorStoreConfig c;
+        c.dimension = dimension;
+        return VectorStore(c);
+    }
+    VectorStore(VectorStore&& o) noexcept { *this = std::move(o); }
+    VectorStore& operator=(VectorStore&& o) noexcept {
+        if (this != &o) {
+            if (h_) trag_store_destroy(h_);
+            h_ = o.h_; o.h_ = nullptr;
+            config_ = o.config_; row_of_ = std::move(o.row_of_); id_of_ = std::move(o.id_of_);
+            chunks_ = std::move(o.chunks_);
+        }
+        return *this;
+    }
+    VectorStore(const VectorStore&) = delete;
+    VectorStore& operator=(const VectorStore&) = delete;
+    ~VectorStore() { if (h_) trag_store_destroy(h_); }
+
+    const VectorStoreConfig& config() const { return config_; }
+
+    // src/index.rs:359-375
+    void insert(Chunk chunk) {
+        if (!chunk.embedding) throw InvalidConfig("chunk must have embedding");
+        const std::vector<float>& e = *chunk.embedding;
+        if (e.size() != config_.dimension) throw DimensionMismatch(config_.dimension, e.size());
+        auto it = row_of_.find(chunk.id);
+        if (it != row_of_.end()) {  // HashMap::insert overwrites
+            check(trag_store_overwrite(h_, it->second, e.data(), (uint32_t)e.size()), config_.dimension, e.size());
+        } else {
+            uint32_t first = 0;
+            check(trag_store_insert(h_, e.data(), 1, (uint32_t)e.size(), &first), config_.dimension, e.size());
+            row_of_[chunk.id] = first;
+            if (id_of_.size() <= first) id_of_.resize(first + 1);
+            id_of_[first] = chunk.id;
+        }
+        const ChunkId id = chunk.id;
+        chunks_.insert_or_assign(id, std::move(chunk));
+    }
+    // src/index.rs:378-383
+    void insert_batch(std::vector<Chunk> chunks) {
+        for (auto& c : chunks) insert(std::move(c));
+    }
+    // src/index.rs:386-412
+    std::vector<std::pair<ChunkId, float>> search(const std::vector<float>& query_vector, size_t k) const {
+        if (query_vector.size() != config_.dimension) throw DimensionMismatch(config_.dimension, query_vector.size());
+        std::vector<uint32_t> rows(k ? k : 1);
+        std::vector<float> scores(k ? k : 1);
+        uint32_t n = 0;
+        check(trag_store_search(h_, query_vector.data(), (uint32_t)query_vector.size(), (uint32_t)k, rows.data(),
+                                scores.data(), &n),
+              config_.dimension, query_vector.size());
+        std::vector<std::pair<ChunkId, float>> out;
+        out.reserve(n);
+        for (uint32_t i = 0; i < n; ++i) out.emplace_back(id_of_[rows[i]], scores[i]);
+        return out;
+    }
+    // src/index.rs:416-418
+    const Chunk* get(ChunkId id) const {
+        auto it = chunks_.find(id);
+        return it == chunks_.end() ? nullptr : &it->second;
+    }
+    // src/index.rs:421-424
+    std::optional<Chunk> remove(ChunkId id) {
+        auto it = row_of_.find(id);
+        if (it == row_of_.end()) return std::nullopt;
+        check(trag_store_remove(h_, it->second));
+        row_of_.erase(it);
+        auto c = chunks_.find(id);
+        std::optional<Chunk> out;
+        if (c != chunks_.end()) { out = std::move(c->second); chunks_.erase(c); }
+        return out;
+    }
+    size_t len() const { return (size_t)trag_store_len(h_); }
+    bool is_empty() const { return len() == 0; }
+    trag_store* handle() const { return h_; }
+
+  private:
+    VectorStoreConfig config_;
+    trag_store* h_ = nullptr;
+    std::unordered_map<ChunkId, uint32_t, ChunkIdHash> row_of_;
+    std::vector<ChunkId> id_of_;
+    std::unordered_map<ChunkId, Chunk, ChunkIdHash> chunks_;
+};
+
+// ---- FusionStrategy (src/fusion.rs:9-63) ----
+struct FusionStrategy {
+    enum Kind : uint32_t { RRF = 0, Linear = 1, Convex = 2, DBSF = 3, Union = 4, Intersection = 5 };
+    Kind kind = RRF;
+    float param = 60.0f;  // k / dense_weight / alpha; Default = RRF{k: 60}, :33-37
+    static FusionStrategy rrf(float k = 60.0f) { return {RRF, k}; }
+    static FusionStrategy linear(float dense_weight) { return {Linear, dense_weight}; }
+    static FusionStrategy convex(float alpha) { return {Convex, alpha}; }
+    static FusionStrategy dbsf() { return {DBSF, 0.0f}; }
+    static FusionStrategy union_() { return {Union, 0.0f}; }
+    static FusionStrategy intersection() { return {Intersection, 0.0f}; }
+
+    using Scored = std::vector<std::pair<ChunkId, float>>;
+    Scored fuse(const Scored& dense_results, const Scored& sparse_results) const {
+        std::unordered_map<ChunkId, uint64_t, ChunkIdHash> tok;
+        std::vector<ChunkId> back;
+        auto token = [&](const ChunkId& id) {
+            auto it = tok.find(id);
+            if (it != tok.end()) return it->second;
+            tok.emplace(id, back.size());
+            back.push_back(id);
+            return (uint64_t)back.size() - 1;
+        };
+        std::vector<uint64_t> di, si;
+        std::vector<float> ds, ss;
+        for (auto& p : dense_results) { di.push_back(token(p.first)); ds.push_back(p.second); }
+        for (auto& p : sparse_results) { si.push_back(token(p.first)); ss.push_back(p.second); }
+        std::vector<uint64_t> oi(di.size() + si.size() + 1);
+        std::vector<float> os(oi.size());
+        uint32_t n = 0;
+        check(trag_fuse(kind, param, di.data(), ds.data(), (uint32_t)di.size(), si.data(), ss.data(),
+                        (uint32_t)si.size(), oi.data(), os.data(), &n));
+        Scored out;
+        for (uint32_t i = 0; i < n; ++i) out.emplace_back(back[oi[i]], os[i]);
+        return out;
+    }
+};
+
+// ---- retrievers (src/retrieve.rs) ----
+struct RetrievalResult {
+    Chunk chunk;
+    std::optional<float> dense_score, sparse_score, fused_score, rerank_score;
+    float best_score() const {  // :69-75
+        if (rerank_score) return *rerank_score;
+        if (fused_score) return *fused_score;
+        if (dense_score) return *dense_score;
+        if (sparse_score) return *sparse_score;
+        return 0.0f;
+    }
+};
+
+struct HybridRetrieverConfig {  // :80-100
+    size_t candidates_per_source = 50;
+    FusionStrategy fusion{};
+    bool use_dense = true, use_sparse = true;
+};
+
+// E: embed_query(const std::string&) -> std::vector<float>   (Embedder, src/embed.rs:55-89)
+// S: add(const Chunk&), search(const std::string&, size_t) -> vector<pair<ChunkId,float>>  (SparseIndex)
+template <class E, class S>
+class HybridRetriever {
+  public:
+    HybridRetriever(VectorStore dense, S sparse, E embedder)
+        : dense_(std::move(dense)), sparse_(std::move(sparse)), embedder_(std::move(embedder)) {}
+    HybridRetriever& with_config(HybridRetrieverConfig c) { config_ = c; return *this; }
+    VectorStore& dense_store() { return dense_; }
+    S& sparse_index() { return sparse_; }
+    void index(Chunk chunk) {  // :156-164
+        sparse_.add(chunk);
+        dense_.insert(std::move(chunk));
+    }
+    void index_batch(std::vector<Chunk> chunks) { for (auto& c : chunks) index(std::move(c)); }
+    std::vector<RetrievalResult> retrieve(const std::string& query, size_t k) {  // :175-220
+        FusionStrategy::Scored dense_results, sparse_results;
+        if (config_.use_dense) dense_results = dense_.search(embedder_.embed_query(query), config_.candidates_per_source);
+        if (config_.use_sparse) sparse_results = sparse_.search(query, config_.candidates_per_source);
+        auto fused = config_.fusion.fuse(dense_results, sparse_results);
+        std::unordered_map<ChunkId, float, ChunkIdHash> dsc(dense_results.begin(), dense_results.end());
+        std::unordered_map<ChunkId, float, ChunkIdHash> ssc(sparse_results.begin(), sparse_results.end());
+        std::vector<RetrievalResult> out;
+        for (size_t i = 0; i < fused.size() && i < k; ++i) {
+            const Chunk* c = dense_.get(fused[i].first);
+            if (!c) continue;  // ids unknown to the dense store are dropped (:205)
+            RetrievalResult r{*c, {}, {}, fused[i].second, {}};
+            if (auto it = dsc.find(fused[i].first); it != dsc.end()) r.dense_score = it->second;
+            if (auto it = ssc.find(fused[i].first); it != ssc.end()) r.sparse_score = it->second;
+            out.push_back(std::move(r));
+        }
+        return out;
+    }
+    std::vector<RetrievalResult> retrieve_dense(const std::string& query, size_t k) {  // :223-235
+        std::vector<RetrievalResult> out;
+        for (auto& p : dense_.search(embedder_.embed_query(query), k))
+            if (const Chunk* c = dense_.get(p.first)) out.push_back(RetrievalResult{*c, p.second, {}, {}, {}});
+        return out;
+    }
+    size_t len() const { return dense_.len(); }
+    bool is_empty() const { return dense_.is_empty(); }
+
+  private:
+    VectorStore dense_;
+    S sparse_;
+    E embedder_;
+    HybridRetrieverConfig config_{};
+};
+
+template <class E>
+class DenseRetriever {  // :266-297
+  public:
+    DenseRetriever(VectorStore store, E embedder) : store_(std::move(store)), embedder_(std::move(embedder)) {}
+    void index(Chunk chunk) { store_.insert(std::move(chunk)); }
+    std::vector<RetrievalResult> retrieve(const std::string& query, size_t k) {
+        std::vector<RetrievalResult> out;
+        for (auto& p : store_.search(embedder_.embed_query(query), k))
+            if (const Chunk* c = store_.get(p.first)) out.push_back(RetrievalResult{*c, p.second, {}, {}, {}});
+        return out;
+    }
+
+  private:
+    VectorStore store_;
+    E embedder_;
+};
+
+}  // namespace trueno_rag

@@ -1,25 +1,5 @@
-# INTEGRATION — dropping libtrag.so into trueno-rag
-
-The reference has no FFI; its dense index is the concrete struct `VectorStore`
-(`src/index.rs:323-437`), handed by value to `HybridRetriever::new` (`src/retrieve.rs:117`),
-`DenseRetriever::new` (`:274`) and `RagPipelineBuilder::vector_store` (`src/pipeline.rs:460`).
-A maintainer swaps in the GPU store by adding one crate (outside the workspace, because the
-workspace sets `unsafe_code = "deny"`, `Cargo.toml:6`) that binds `include/trag.h` and exposes a
-type with `VectorStore`'s method names, then replacing `use crate::index::VectorStore` in
-`src/retrieve.rs:6` / `src/pipeline.rs` by that type (or making the two retrievers generic over a
-small `DenseIndex` trait with the five methods they call: `insert`, `search`, `get`, `len`, `is_empty`).
-
-Build and link: `make -C trueno-rag_amd/csrc` → `trueno-rag_amd/lib/libtrag.so` (needs ROCm ≥ 7.0,
-`hipcc --offload-arch=gfx950`). `build.rs`: `println!("cargo:rustc-link-lib=dylib=trag");` plus a
-`rustc-link-search` to that directory.
-
-## Rust binding (source only — there is no rustc in the build image, so this is uncompiled)
-
-The same source lives in `trueno-rag_amd/rust/trueno-rag-hip/` (`Cargo.toml`, `build.rs`, `src/lib.rs`).
-A compiled C++ equivalent with the same surface is `trueno-rag_amd/host/trueno_rag.hpp` (tested on the GPU by
-`tests/test_gpu_cpp_host.py`).
-
-```rust
+//! GPU-backed drop-in for trueno_rag::index::VectorStore over libtrag.so (include/trag.h).
+//! UNCOMPILED: the image that produced this repository has no Rust toolchain.
 // trueno-rag-hip/src/lib.rs
 #![allow(unsafe_code)]
 use std::collections::HashMap;
@@ -129,36 +109,3 @@ impl GpuVectorStore {
     pub fn is_empty(&self) -> bool { self.len() == 0 }
 }
 impl Drop for GpuVectorStore { fn drop(&mut self) { unsafe { trag_store_destroy(self.h) } } }
-```
-
-`FusionStrategy::fuse` (`src/fusion.rs:42-63`) maps to `trag_fuse(strategy, param, …)` with ids replaced
-by positions in a local id table (as `trueno-rag_amd/fusion.py` does); it is host code, so the Rust
-implementation can equally stay as it is — results are identical except that exact score ties come out
-in first-appearance order instead of hash order.
-
-`Clone` for the store: implement as a deep copy (`trag_store_read_rows` + `trag_store_insert`) or wrap
-the handle in `Arc`; the reference derives `Clone` (`src/index.rs:322`) but never clones a store on the
-path.
-
-## Other hosts
-
-- **C / C++**: include `include/trag.h`, link `-ltrag`. All pointers are host pointers unless the entry
-  point's name ends in `_device`.
-- **Python (ctypes)**: `trueno-rag_amd/_abi.py` declares every symbol; `index.py`, `retrieve.py`,
-  `fusion.py` mirror the reference's types. In a process that also uses PyTorch, import torch before
-  loading `libtrag.so` (the binding does): PyTorch wheels bundle their own `libamdhip64` and both must
-  share one HIP runtime for device pointers and streams to be interchangeable.
-- **Device-resident callers** (queries produced on the GPU by an embedder): `trag_store_search_device`
-  enqueues on the caller's stream and returns immediately; statuses and results stay in device memory.
-  Queries must be 16-byte aligned. All device-entry calls on one handle must use the same stream (they share
-  the handle's scratch).
-
-## Behavioural differences a maintainer should know
-
-- Tie order is deterministic (ascending insertion row) where the reference's is HashMap order.
-- NaN scores rank last; the reference's order for NaN is unspecified.
-- `remove` tombstones a row; memory is reclaimed only by rebuilding the store.
-- `k` above ≈ 4000 (with more than 4096 live rows) is served by a slower path: exact scan + a global sort of
-  every row's rank key (tens of ms at 10 M rows). The reference's callers ask for ≤ 100.
-- A process without a visible MI355X/ROCm device gets `TRAG_DEVICE_ERROR` from `trag_store_create`: there is
-  deliberately no CPU fallback.
