@@ -89,12 +89,16 @@ def main():
     sptr = stream.cuda_stream
     esz = 4
     ex = None
-    if world > 1:
+    # TRAG_BENCH_FORCE_EXCHANGE=1 runs the pack / gather / merge leg on one GPU too (world size 1)
+    if world > 1 or os.environ.get("TRAG_BENCH_FORCE_EXCHANGE"):
         from trueno_rag_amd.sharded import ShardExchange
         ex = ShardExchange(k, max_queries=B, device=torch.device("cuda", local))
         m_rows = torch.zeros((n_q, k), dtype=torch.int32, device="cuda")
         m_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
         m_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+        # the exchange of step i runs on a side stream while the scan of step i+1 runs on the
+        # main one (the merged results are only consumed after the final synchronize)
+        side = torch.cuda.Stream()
 
     hybrid_out = []
     if args.hybrid:
@@ -128,8 +132,12 @@ def main():
                             out_scores.data_ptr() + i * k * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
         if ex is not None:  # pack, ONE all-gather for the step's queries, device merge
-            ex.exchange(out_rows[i:i + B], out_scores[i:i + B], out_n[i:i + B], row0,
-                        m_rows[i:i + B], m_scores[i:i + B], m_n[i:i + B], sptr)
+            done = torch.cuda.Event()
+            done.record(stream)
+            side.wait_event(done)
+            with torch.cuda.stream(side):
+                ex.exchange(out_rows[i:i + B], out_scores[i:i + B], out_n[i:i + B], row0,
+                            m_rows[i:i + B], m_scores[i:i + B], m_n[i:i + B], side.cuda_stream)
 
     def fence():
         torch.cuda.synchronize()
