@@ -37,8 +37,11 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 matrix cores")
     ap.add_argument("--batch", type=int, default=1, help="queries per step (>= 8: matrix-core path)")
+    ap.add_argument("--sparse-vocab", type=int, default=50000)
+    ap.add_argument("--sparse-tokens", type=int, default=64)
+    ap.add_argument("--sparse-terms", type=int, default=8)
     ap.add_argument("--hybrid", action="store_true",
-                    help="hybrid step: dense top-50 + a synthetic sparse top-50 list -> RRF(60) -> top-k on the host")
+                    help="hybrid step: dense top-50 + BM25 top-50 (synthetic documents) -> RRF(60) -> top-k on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     return ap.parse_args()
@@ -101,27 +104,36 @@ def main():
         side = torch.cuda.Stream()
 
     hybrid_out = []
+    sparse_info = None
     if args.hybrid:
         assert world == 1 and B == 1, "--hybrid is a single-GPU, single-query step"
         cand = 50  # HybridRetrieverConfig::candidates_per_source, src/retrieve.rs:94
-        rng = np.random.default_rng(seed + 7)
         fusion = pkg.FusionStrategy.RRF(60.0)
         h_rows = torch.zeros((n_q, cand), dtype=torch.int32, device="cuda")
         h_scores = torch.zeros((n_q, cand), dtype=torch.float32, device="cuda")
+        # the sparse half: one synthetic document per corpus row (Zipf(1.0) over the vocabulary),
+        # queries drawn from the same law
+        bm25 = pkg.BM25Index(device=local)
+        t_build = time.perf_counter()
+        bm25.fill_synthetic(n_local, args.sparse_vocab, args.sparse_tokens, seed + 1, first_global_doc=row0)
+        bm25.search_ids([0], 1)  # builds and uploads the inverted lists
+        t_build = time.perf_counter() - t_build
+        q_terms = sparse_queries(n_q, args.sparse_vocab, args.sparse_terms, seed + 101)
+        sparse_info = {"documents": n_local, "vocab": args.sparse_vocab, "tokens_per_doc": args.sparse_tokens,
+                       "query_terms": args.sparse_terms, "postings": bm25.stats()["postings"],
+                       "build_seconds": t_build}
 
     def hybrid_step(i):
-        """src/retrieve.rs:175-220 with the BM25 list replaced by a seeded list that shares
-        ~30% of its ids with the dense list (the sparse index itself is CPU work in the reference)."""
+        """src/retrieve.rs:175-220: dense top-50 and BM25 top-50 (both on the GPU, on two
+        streams), then RRF(60) and the cut to k on the host."""
         store.search_device(Q.data_ptr() + i * d * esz, 1, cand, h_rows.data_ptr() + i * cand * esz,
                             h_scores.data_ptr() + i * cand * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
+        s_docs, s_scores = bm25.search_ids(q_terms[i], cand)   # overlaps the dense scan
         rows = h_rows[i].cpu().numpy()          # synchronises: the fusion runs on the host
         scores = h_scores[i].cpu().numpy()
         dense = list(zip(rows.tolist(), scores.tolist()))
-        shared = rng.choice(rows, size=15, replace=False)
-        fresh = rng.integers(0, n_local, size=35)
-        sparse_ids = rng.permutation(np.concatenate([shared, fresh]))
-        sparse = [(int(r), 10.0 - 0.1 * j) for j, r in enumerate(sparse_ids)]
+        sparse = list(zip(s_docs.tolist(), s_scores.tolist()))
         hybrid_out.append(fusion.fuse(dense, sparse)[:k])
 
     def step(s):
@@ -198,8 +210,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"{n_total}x{d} fp32 corpus in HBM, hybrid step: dense cosine top-50 + synthetic "
-                                    f"sparse top-50 -> RRF(60) on the host -> top-{args.k}") if args.hybrid else
+            "config": {"workload": (f"{n_total}x{d} fp32 corpus in HBM, hybrid step: dense cosine top-50 + BM25 "
+                                    f"top-50 over {n_total} synthetic documents (both on the GPU) -> RRF(60) on "
+                                    f"the host -> top-{args.k}") if args.hybrid else
                        f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, cosine top-{k}",
                        "rows": n_total, "dim": d, "k": k, "batch": B, "metric": "cosine",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
@@ -212,6 +225,12 @@ def main():
 
             "parity": parity,
         }
+        if sparse_info is not None:
+            t0 = time.perf_counter()
+            for i in range(20):
+                bm25.search_ids(q_terms[i % len(q_terms)], cand)
+            sparse_info["search_ms_alone"] = 1e3 * (time.perf_counter() - t0) / 20
+            result["config"]["sparse"] = sparse_info
         result["roofline"].update({"kernel": "scan (corpus pass)", "kernel_avg_ms": scan_avg_ms,
                                    "launches_timed": scan_launches, "algorithmic_bytes_per_launch": algo_bytes,
                                    "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9})
@@ -222,6 +241,14 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sparse_queries(n, vocab, n_terms, seed):
+    """n queries of n_terms term ids, Zipf(1.0) over the vocabulary (numpy, seeded)."""
+    rng = np.random.default_rng(seed)
+    cdf = np.cumsum(1.0 / np.arange(1, vocab + 1))
+    u = rng.random((n, n_terms)) * cdf[-1]
+    return np.minimum(np.searchsorted(cdf, u, side="right"), vocab - 1).astype(np.uint32)
 
 
 def cpu_baseline(store, Q, n_local, n_total, d, k, sample_rows, gpu_rows_last):

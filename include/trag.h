@@ -200,6 +200,74 @@ typedef struct trag_search_stats {
 } trag_search_stats;
 trag_status trag_store_last_stats(const trag_store *s, trag_search_stats *out);
 
+/* ------------------------------------------------------------------------
+ * BM25 sparse index (the sparse half of the hybrid retrieve,
+ * src/retrieve.rs:183-187). Replaces `BM25Index` (src/index.rs:31-51) behind
+ * its `SparseIndex` trait (src/index.rs:8-28).
+ *
+ * The boundary works on TERM IDS: the host side keeps the reference's
+ * tokenizer (`BM25Index::tokenize`, src/index.rs:111-124) and a term -> u32
+ * dictionary, and hands documents and queries over as id sequences.
+ * Documents are numbered in insertion order (u32), like store rows. Postings
+ * (CSR by term: document, term frequency) and document lengths live in HBM;
+ * a query is scored there and the top k selected with the dense path's select.
+ * ------------------------------------------------------------------------ */
+typedef struct trag_bm25 trag_bm25;
+
+typedef struct trag_bm25_config {
+    float k1;        /* term-frequency saturation; reference default 1.2 (src/index.rs:69) */
+    float b;         /* length normalisation; reference default 0.75 (src/index.rs:70) */
+    int32_t device;  /* HIP device ordinal; -1 = current device */
+} trag_bm25_config;
+
+/* `BM25Index::new` / `with_params` (src/index.rs:62-84). */
+trag_status trag_bm25_create(const trag_bm25_config *cfg, trag_bm25 **out);
+void trag_bm25_destroy(trag_bm25 *ix);
+
+/* `SparseIndex::add` / `add_batch` (src/index.rs:176-210) for n_docs tokenised
+ * documents: document i owns terms[doc_offsets[i] .. doc_offsets[i+1]) (its
+ * tokens in order, repeats included; its length is that token count). Returns
+ * the index of the first new document. An empty document still counts
+ * towards the document count and the average length, as in the reference. */
+trag_status trag_bm25_add(trag_bm25 *ix, const uint32_t *terms, const uint64_t *doc_offsets,
+                          uint64_t n_docs, uint32_t *out_first_doc);
+
+/* `SparseIndex::remove` (src/index.rs:245-275): the document stops matching
+ * and no longer counts in document frequencies, the document count or the
+ * average length. Removing an unknown or already removed document is not an
+ * error. */
+trag_status trag_bm25_remove(trag_bm25 *ix, uint32_t doc);
+
+/* `SparseIndex::len` (src/index.rs:277-279): documents added and not removed. */
+uint64_t trag_bm25_len(const trag_bm25 *ix);
+
+/* `SparseIndex::search` (src/index.rs:212-243) for a tokenised query (its
+ * terms in order, repeats included: a repeated term counts twice, as in the
+ * reference). Writes min(k, documents with score > 0) results, best first;
+ * equal scores by ascending document index. Unknown terms match nothing; an
+ * empty query returns nothing. */
+trag_status trag_bm25_search(trag_bm25 *ix, const uint32_t *query_terms, uint32_t n_terms, uint32_t k,
+                             uint32_t *out_docs, float *out_scores, uint32_t *out_n);
+
+/* Same search with device-resident outputs (k entries + 1 count + 1 status
+ * word), enqueued on hip_stream without synchronising. *d_status follows
+ * trag_store_search_device's codes; 3 asks the caller to use trag_bm25_search
+ * for this query (crowded score bins need the multi-level select). */
+trag_status trag_bm25_search_device(trag_bm25 *ix, const uint32_t *query_terms, uint32_t n_terms,
+                                    uint32_t k, uint32_t *d_out_docs, float *d_out_scores,
+                                    uint32_t *d_out_n, uint32_t *d_status, void *hip_stream);
+
+/* Benchmark input: n_docs synthetic documents of tokens_per_doc tokens drawn
+ * from Zipf(1.0) over vocab terms (term 0 the most frequent), token p of
+ * document i a pure function of (seed, first_global_doc + i, p). No
+ * counterpart in the reference. */
+trag_status trag_bm25_fill_synthetic(trag_bm25 *ix, uint64_t n_docs, uint32_t vocab,
+                                     uint32_t tokens_per_doc, uint64_t seed,
+                                     uint64_t first_global_doc, uint32_t *out_first_doc);
+
+/* Diagnostics: postings held, distinct terms with at least one posting. */
+trag_status trag_bm25_stats(trag_bm25 *ix, uint64_t *postings, uint64_t *terms);
+
 const char *trag_last_error(void);
 const char *trag_version(void);
 

@@ -17,8 +17,8 @@ FUSE_RRF, FUSE_LINEAR, FUSE_CONVEX, FUSE_DBSF, FUSE_UNION, FUSE_INTERSECTION = r
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "trag_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("trag_oracle.c", "trag_oracle_bm25.c")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(map(os.path.getmtime, srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -58,6 +58,11 @@ def lib():
         L.oracle_num_threads.restype = C.c_int
         L.oracle_bench_faithful.restype = C.c_double
         L.oracle_bench_faithful.argtypes = [fp, C.c_uint64, C.c_uint32, C.c_int, fp, C.c_uint32, C.c_uint32, u32p, fp]
+        L.oracle_bm25_search.restype = C.c_uint32
+        L.oracle_bm25_search.argtypes = [u32p, u64p, C.c_uint64, u8p, C.c_float, C.c_float, u32p, C.c_uint32,
+                                         C.c_uint32, u32p, fp]
+        L.oracle_bm25_synth_docs.restype = None
+        L.oracle_bm25_synth_docs.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, u32p]
         _lib = L
     return _lib
 
@@ -170,3 +175,30 @@ def bench_faithful(corpus, queries, k, metric=COSINE):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def bm25_search(terms, doc_offsets, q_terms, k, k1=1.2, b=0.75, removed=None):
+    """BM25 over tokenised documents (src/index.rs:212-243 of the reference):
+    returns (document indices, scores), best first, ties by ascending document."""
+    terms = np.ascontiguousarray(terms, dtype=np.uint32)
+    off = np.ascontiguousarray(doc_offsets, dtype=np.uint64)
+    q = np.ascontiguousarray(q_terms, dtype=np.uint32)
+    n_docs = len(off) - 1
+    rm = None
+    if removed is not None:
+        rm = np.ascontiguousarray(removed, dtype=np.uint8)
+        assert rm.shape == (n_docs,)
+    docs = np.empty(max(k, 1), dtype=np.uint32)
+    scores = np.empty(max(k, 1), dtype=np.float32)
+    tp = _p(terms, C.c_uint32) if terms.size else _p(np.zeros(1, np.uint32), C.c_uint32)
+    qp = _p(q, C.c_uint32) if q.size else _p(np.zeros(1, np.uint32), C.c_uint32)
+    n = lib().oracle_bm25_search(tp, _p(off, C.c_uint64), n_docs, _p(rm, C.c_uint8) if rm is not None else None,
+                                 k1, b, qp, q.size, k, _p(docs, C.c_uint32), _p(scores, C.c_float))
+    return docs[:n].copy(), scores[:n].copy()
+
+
+def bm25_synth_docs(seed, doc0, n_docs, vocab, tokens_per_doc):
+    """Zipf(1.0) token ids, shape (n_docs, tokens_per_doc)."""
+    out = np.empty((n_docs, tokens_per_doc), dtype=np.uint32)
+    lib().oracle_bm25_synth_docs(seed, doc0, n_docs, vocab, tokens_per_doc, _p(out, C.c_uint32))
+    return out

@@ -37,6 +37,10 @@ class Config(C.Structure):
                 ("scan_mode", C.c_uint32), ("reserve_rows", C.c_uint64)]
 
 
+class BM25Config(C.Structure):
+    _fields_ = [("k1", C.c_float), ("b", C.c_float), ("device", C.c_int32)]
+
+
 class SearchStats(C.Structure):
     _fields_ = [("mode_used", C.c_uint32), ("candidates", C.c_uint32),
                 ("refine_levels", C.c_uint32), ("fallbacks", C.c_uint32)]
@@ -75,6 +79,17 @@ SIGNATURES = {
     "trag_fuse_rrf": (C.c_int, [_u64p, C.c_uint32, _u64p, C.c_uint32, C.c_float, _u64p, _fp, _u32p]),
     "trag_merge_topk": (C.c_int, [_u32p, _fp, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
     "trag_store_last_stats": (C.c_int, [_H, C.POINTER(SearchStats)]),
+    "trag_bm25_create": (C.c_int, [C.POINTER(BM25Config), C.POINTER(_H)]),
+    "trag_bm25_destroy": (None, [_H]),
+    "trag_bm25_add": (C.c_int, [_H, _u32p, _u64p, C.c_uint64, _u32p]),
+    "trag_bm25_remove": (C.c_int, [_H, C.c_uint32]),
+    "trag_bm25_len": (C.c_uint64, [_H]),
+    "trag_bm25_search": (C.c_int, [_H, _u32p, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "trag_bm25_search_device": (C.c_int, [_H, _u32p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trag_bm25_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
+                                           _u32p]),
+    "trag_bm25_stats": (C.c_int, [_H, _u64p, _u64p]),
     "trag_last_error": (C.c_char_p, []),
     "trag_version": (C.c_char_p, []),
 }

@@ -27,6 +27,14 @@ trag_status fail(trag_status st, const std::string& msg) {
     return st;
 }
 
+}  // namespace
+
+namespace trag {
+trag_status set_error(trag_status st, const std::string& msg) { return fail(st, msg); }
+}  // namespace trag
+
+namespace {
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

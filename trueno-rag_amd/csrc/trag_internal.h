@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <string>
 #include "trag.h"
 
 namespace trag {
@@ -77,6 +78,9 @@ struct ScanArgs {
     uint32_t dim;
     uint32_t metric;
 };
+
+// Records the calling thread's error message (read back by trag_last_error) and returns st.
+trag_status set_error(trag_status st, const std::string& msg);
 
 // ---- kernel launchers (trag_kernels.hip) ----
 // the scans report the number of waves of their grid (tile t is scanned by wave t % n_waves)
