@@ -1,6 +1,7 @@
 // The reference's VectorStore / fusion / retriever unit tests (src/index.rs:667-867,
 // src/fusion.rs:267-325, src/retrieve.rs:464-531) driven through the C++ host mirror.
 // Needs a GPU. Exit code 0 = all passed.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <string>
@@ -108,6 +109,41 @@ int main() {
         DenseRetriever<StubEmbedder> dr(VectorStore::with_dimension(3), StubEmbedder{});
         dr.index(chunk_with("beta", {0, 1, 0}));
         EXPECT(dr.retrieve("b", 5).size() == 1);
+    }
+    {   // BM25Index: src/index.rs:481-665
+        BM25Index ix;
+        EXPECT(ix.len() == 0 && ix.is_empty() && std::fabs(ix.k1 - 1.2f) < 0.01f && std::fabs(ix.b - 0.75f) < 0.01f);
+        BM25Index p = BM25Index::with_params(1.5f, 0.5f);
+        EXPECT(std::fabs(p.k1 - 1.5f) < 0.01f && std::fabs(p.b - 0.5f) < 0.01f);
+        auto toks = ix.tokenize("Hello World! This is a test.");
+        auto has = [&](const char* w) { return std::find(toks.begin(), toks.end(), std::string(w)) != toks.end(); };
+        EXPECT(has("hello") && has("world") && has("test") && !has("this") && !has("is") && !has("a"));
+        Chunk c1("Machine learning algorithms"), c2("Deep learning neural networks"), c3("Natural language processing");
+        ix.add(c1); ix.add(c2); ix.add(c3);
+        EXPECT(ix.len() == 3 && ix.has_term("machine") && ix.has_term("learning"));
+        auto r = ix.search("machine learning", 10);
+        EXPECT(!r.empty() && r[0].first == c1.id);
+        EXPECT(ix.search("", 10).empty() && ix.search("the a an", 10).empty() && ix.search("quantum physics", 10).empty());
+        BM25Index rk;
+        Chunk p1("python programming language"), p2("python python python programming");
+        rk.add(p1); rk.add(p2);
+        auto rr = rk.search("python programming", 10);
+        EXPECT(rr.size() == 2 && rr[0].first == p2.id);
+        BM25Index tk;
+        for (int i = 0; i < 10; ++i) tk.add(Chunk("document " + std::to_string(i) + " about rust"));
+        EXPECT(tk.search("rust", 3).size() == 3);
+        BM25Index rm;
+        Chunk t("Test document");
+        rm.add(t);
+        rm.remove(t.id);
+        EXPECT(rm.len() == 0 && rm.search("test", 10).empty());
+        // hybrid retriever with the real sparse index, src/retrieve.rs:175-220
+        HybridRetriever<StubEmbedder, BM25Index> hr(VectorStore::with_dimension(3), BM25Index(), StubEmbedder{});
+        std::vector<Chunk> cs = {chunk_with("alpha particles", {1, 0, 0}), chunk_with("beta decay", {0, 1, 0}),
+                                 chunk_with("gamma rays and beta decay", {0, 0, 1})};
+        hr.index_batch(cs);
+        auto res = hr.retrieve("beta decay", 3);
+        EXPECT(res.size() == 3 && res[0].chunk.id == cs[1].id && res[0].sparse_score.has_value());
     }
     std::printf(failures ? "%d failure(s)\n" : "host mirror: all checks passed\n", failures);
     return failures ? 1 : 0;

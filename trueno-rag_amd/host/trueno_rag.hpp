@@ -2,6 +2,7 @@
 // retrieval path, over the C ABI of include/trag.h. Names, argument meaning
 // and error behaviour follow the reference (paths relative to its tree):
 //   VectorStore, VectorStoreConfig, DistanceMetric     src/index.rs:282-437
+//   BM25Index (SparseIndex)                             src/index.rs:7-280
 //   FusionStrategy                                      src/fusion.rs:9-63
 //   RetrievalResult, HybridRetrieverConfig,
 //   HybridRetriever, DenseRetriever                     src/retrieve.rs:13-297
@@ -14,6 +15,7 @@
 #include <stdexcept>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -163,6 +165,116 @@ class VectorStore {
     std::unordered_map<ChunkId, uint32_t, ChunkIdHash> row_of_;
     std::vector<ChunkId> id_of_;
     std::unordered_map<ChunkId, Chunk, ChunkIdHash> chunks_;
+};
+
+// ---- BM25Index (src/index.rs:31-280) ----
+// Tokenizer and term dictionary on the host, scoring and top-k on the GPU
+// (trag_bm25_*). The tokenizer here classifies ASCII letters and digits as
+// alphanumeric and treats every byte >= 0x80 as part of a token (so UTF-8
+// words stay whole); lower-casing is ASCII only. The reference uses Unicode
+// char::is_alphanumeric / to_lowercase (src/index.rs:112-116): identical on
+// ASCII text.
+class BM25Index {
+  public:
+    BM25Index() : BM25Index(1.2f, 0.75f) {}  // BM25Index::new, :62-74
+    static BM25Index with_params(float k1, float b) { return BM25Index(k1, b); }  // :78-84
+    BM25Index(float k1_, float b_) : k1(k1_), b(b_), stopwords_(default_stopwords()) {
+        trag_bm25_config c{k1_, b_, -1};
+        check(trag_bm25_create(&c, &h_));
+    }
+    BM25Index(BM25Index&& o) noexcept
+        : k1(o.k1), b(o.b), h_(o.h_), stopwords_(std::move(o.stopwords_)), terms_(std::move(o.terms_)),
+          docs_of_(std::move(o.docs_of_)), id_of_(std::move(o.id_of_)) { o.h_ = nullptr; }
+    BM25Index(const BM25Index&) = delete;
+    BM25Index& operator=(const BM25Index&) = delete;
+    ~BM25Index() { if (h_) trag_bm25_destroy(h_); }
+
+    BM25Index with_stopwords(std::unordered_set<std::string> stopwords) && {  // :88-91
+        stopwords_ = std::move(stopwords);
+        return std::move(*this);
+    }
+
+    std::vector<std::string> tokenize(const std::string& text) const {  // :111-124
+        std::vector<std::string> out;
+        std::string cur;
+        auto flush = [&]() {
+            if (!cur.empty() && !stopwords_.count(cur) && cur.size() >= 2) out.push_back(cur);
+            cur.clear();
+        };
+        for (unsigned char ch : text) {
+            const bool alnum = (ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || ch >= 0x80;
+            if (alnum) cur.push_back((ch >= 'A' && ch <= 'Z') ? (char)(ch + 32) : (char)ch);
+            else flush();
+        }
+        flush();
+        return out;
+    }
+
+    void add(const Chunk& chunk) {  // :176-204
+        const std::vector<uint32_t> ids = term_ids(tokenize(chunk.content), true);
+        const uint64_t off[2] = {0, ids.size()};
+        const uint32_t dummy = 0;
+        uint32_t first = 0;
+        check(trag_bm25_add(h_, ids.empty() ? &dummy : ids.data(), off, 1, &first));
+        docs_of_[chunk.id].push_back(first);
+        if (id_of_.size() <= first) id_of_.resize((size_t)first + 1);
+        id_of_[first] = chunk.id;
+    }
+    void add_batch(const std::vector<Chunk>& chunks) { for (const auto& c : chunks) add(c); }  // :206-210
+
+    std::vector<std::pair<ChunkId, float>> search(const std::string& query, size_t k) const {  // :212-243
+        const std::vector<std::string> toks = tokenize(query);
+        std::vector<std::pair<ChunkId, float>> out;
+        if (toks.empty() || k == 0) return out;
+        const std::vector<uint32_t> ids = const_cast<BM25Index*>(this)->term_ids(toks, false);
+        std::vector<uint32_t> docs(k);
+        std::vector<float> scores(k);
+        uint32_t n = 0;
+        check(trag_bm25_search(h_, ids.data(), (uint32_t)ids.size(), (uint32_t)k, docs.data(), scores.data(), &n));
+        for (uint32_t i = 0; i < n; ++i) out.emplace_back(id_of_[docs[i]], scores[i]);
+        return out;
+    }
+
+    void remove(ChunkId chunk_id) {  // :245-275
+        auto it = docs_of_.find(chunk_id);
+        if (it == docs_of_.end()) return;
+        for (uint32_t d : it->second) check(trag_bm25_remove(h_, d));
+        docs_of_.erase(it);
+    }
+    size_t len() const { return (size_t)trag_bm25_len(h_); }  // :277-279
+    bool is_empty() const { return len() == 0; }               // :25-27
+    bool has_term(const std::string& t) const { return terms_.count(t) != 0; }
+
+    float k1, b;
+
+  private:
+    static std::unordered_set<std::string> default_stopwords() {  // :93-108
+        static const char* w[] = {
+            "a", "an", "the", "is", "are", "was", "were", "be", "been", "being", "have", "has", "had", "do", "does",
+            "did", "will", "would", "could", "should", "may", "might", "must", "shall", "can", "need", "dare", "ought",
+            "used", "to", "of", "in", "for", "on", "with", "at", "by", "from", "as", "into", "through", "during",
+            "before", "after", "above", "below", "between", "under", "again", "further", "then", "once", "here",
+            "there", "when", "where", "why", "how", "all", "each", "few", "more", "most", "other", "some", "such", "no",
+            "nor", "not", "only", "own", "same", "so", "than", "too", "very", "just", "and", "but", "if", "or",
+            "because", "until", "while", "this", "that", "these", "those", "it", "its"};
+        return std::unordered_set<std::string>(std::begin(w), std::end(w));
+    }
+    std::vector<uint32_t> term_ids(const std::vector<std::string>& toks, bool create) {
+        std::vector<uint32_t> ids;
+        ids.reserve(toks.size());
+        for (const auto& t : toks) {
+            auto it = terms_.find(t);
+            if (it != terms_.end()) ids.push_back(it->second);
+            else if (create) { const uint32_t id = (uint32_t)terms_.size(); terms_.emplace(t, id); ids.push_back(id); }
+            else ids.push_back(0x0FFFFFFFu);  // never assigned: matches nothing
+        }
+        return ids;
+    }
+    trag_bm25* h_ = nullptr;
+    std::unordered_set<std::string> stopwords_;
+    std::unordered_map<std::string, uint32_t> terms_;
+    std::unordered_map<ChunkId, std::vector<uint32_t>, ChunkIdHash> docs_of_;
+    std::vector<ChunkId> id_of_;
 };
 
 // ---- FusionStrategy (src/fusion.rs:9-63) ----

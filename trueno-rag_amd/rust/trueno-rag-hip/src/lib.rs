@@ -109,3 +109,82 @@ impl GpuVectorStore {
     pub fn is_empty(&self) -> bool { self.len() == 0 }
 }
 impl Drop for GpuVectorStore { fn drop(&mut self) { unsafe { trag_store_destroy(self.h) } } }
+
+// ---------------------------------------------------------------------------
+// BM25: `impl SparseIndex for GpuBm25Index` (src/index.rs:8-28, 175-280).
+// The tokenizer is the reference's own (`BM25Index::tokenize`, a pub fn,
+// src/index.rs:111-124): a default `BM25Index` is kept only to call it.
+// ---------------------------------------------------------------------------
+#[repr(C)]
+struct TragBm25Config { k1: f32, b: f32, device: i32 }
+#[repr(C)] pub struct TragBm25 { _p: [u8; 0] }
+
+extern "C" {
+    fn trag_bm25_create(cfg: *const TragBm25Config, out: *mut *mut TragBm25) -> i32;
+    fn trag_bm25_destroy(ix: *mut TragBm25);
+    fn trag_bm25_add(ix: *mut TragBm25, terms: *const u32, doc_offsets: *const u64, n_docs: u64,
+                     first: *mut u32) -> i32;
+    fn trag_bm25_remove(ix: *mut TragBm25, doc: u32) -> i32;
+    fn trag_bm25_len(ix: *const TragBm25) -> u64;
+    fn trag_bm25_search(ix: *mut TragBm25, q: *const u32, n_terms: u32, k: u32,
+                        docs: *mut u32, scores: *mut f32, n: *mut u32) -> i32;
+}
+
+pub struct GpuBm25Index {
+    h: *mut TragBm25,
+    tokenizer: trueno_rag::index::BM25Index,   // never indexed into; tokenize() only
+    terms: HashMap<String, u32>,               // term -> id
+    docs_of: HashMap<ChunkId, Vec<u32>>,       // a re-added id owns several documents
+    id_of: Vec<ChunkId>,
+}
+unsafe impl Send for GpuBm25Index {}
+unsafe impl Sync for GpuBm25Index {}
+
+impl GpuBm25Index {
+    pub fn new() -> Self { Self::with_params(1.2, 0.75) }
+    pub fn with_params(k1: f32, b: f32) -> Self {
+        let c = TragBm25Config { k1, b, device: -1 };
+        let mut h = std::ptr::null_mut();
+        let rc = unsafe { trag_bm25_create(&c, &mut h) };
+        assert_eq!(rc, 0, "trag_bm25_create: {:?}", err(rc, 0, 0));   // `new` is infallible in the reference
+        Self { h, tokenizer: trueno_rag::index::BM25Index::with_params(k1, b), terms: HashMap::new(),
+               docs_of: HashMap::new(), id_of: Vec::new() }
+    }
+    fn ids(&mut self, tokens: Vec<String>, create: bool) -> Vec<u32> {
+        tokens.into_iter().map(|t| {
+            if let Some(&i) = self.terms.get(&t) { i }
+            else if create { let i = self.terms.len() as u32; self.terms.insert(t, i); i }
+            else { 0x0FFF_FFFF }                                      // never assigned: matches nothing
+        }).collect()
+    }
+}
+
+impl trueno_rag::index::SparseIndex for GpuBm25Index {
+    fn add(&mut self, chunk: &Chunk) {
+        let toks = self.tokenizer.tokenize(&chunk.content);
+        let ids = self.ids(toks, true);
+        let off = [0u64, ids.len() as u64];
+        let mut first = 0u32;
+        let p = if ids.is_empty() { [0u32].as_ptr() } else { ids.as_ptr() };
+        let rc = unsafe { trag_bm25_add(self.h, p, off.as_ptr(), 1, &mut first) };
+        assert_eq!(rc, 0, "trag_bm25_add: {:?}", err(rc, 0, 0));
+        self.docs_of.entry(chunk.id).or_default().push(first);
+        self.id_of.push(chunk.id);
+    }
+    fn add_batch(&mut self, chunks: &[Chunk]) { for c in chunks { self.add(c); } }   // or one call, n_docs = len
+    fn search(&self, query: &str, k: usize) -> Vec<(ChunkId, f32)> {
+        let toks = self.tokenizer.tokenize(query);
+        if toks.is_empty() || k == 0 { return Vec::new(); }
+        let ids: Vec<u32> = toks.iter().map(|t| *self.terms.get(t).unwrap_or(&0x0FFF_FFFF)).collect();
+        let (mut docs, mut scores, mut n) = (vec![0u32; k], vec![0f32; k], 0u32);
+        let rc = unsafe { trag_bm25_search(self.h, ids.as_ptr(), ids.len() as u32, k as u32,
+                                           docs.as_mut_ptr(), scores.as_mut_ptr(), &mut n) };
+        if rc != 0 { return Vec::new(); }                             // the trait has no error channel
+        (0..n as usize).map(|i| (self.id_of[docs[i] as usize], scores[i])).collect()
+    }
+    fn remove(&mut self, chunk_id: ChunkId) {
+        for d in self.docs_of.remove(&chunk_id).unwrap_or_default() { unsafe { trag_bm25_remove(self.h, d) }; }
+    }
+    fn len(&self) -> usize { unsafe { trag_bm25_len(self.h) as usize } }
+}
+impl Drop for GpuBm25Index { fn drop(&mut self) { unsafe { trag_bm25_destroy(self.h) } } }
