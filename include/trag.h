@@ -268,6 +268,15 @@ trag_status trag_bm25_fill_synthetic(trag_bm25 *ix, uint64_t n_docs, uint32_t vo
 /* Diagnostics: postings held, distinct terms with at least one posting. */
 trag_status trag_bm25_stats(trag_bm25 *ix, uint64_t *postings, uint64_t *terms);
 
+/* `MockEmbedder::hash_to_vector` (src/embed.rs:124-155), the input generator
+ * of the reference's tests and of benches/retrieval.rs: dim values from one
+ * running SipHash-1-3 (std's DefaultHasher, zero keys) over (text, i) pairs,
+ * mapped to [-1, 1], L2-normalised when `normalize` is nonzero
+ * (EmbeddingConfig::normalize, default true, src/embed.rs:41-48). Host code;
+ * needs no GPU. The reference pins only length, unit norm, determinism and
+ * text sensitivity of these vectors (src/embed.rs:992-1036), not their values. */
+trag_status trag_mock_embed(const char *text, uint64_t len, uint32_t dim, int normalize, float *out);
+
 const char *trag_last_error(void);
 const char *trag_version(void);
 

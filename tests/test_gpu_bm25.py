@@ -226,3 +226,20 @@ def test_hybrid_retriever_with_bm25(trag, oracle):
     sparse = {chunks[int(i)].id: float(s) for i, s in zip(sd, ss)}
     for x in out:
         assert x.sparse_score == sparse.get(x.chunk.id)
+
+
+def test_reference_bench_shape(trag):
+    """benches/retrieval.rs:44-68: 1000 documents "Document {i} about topic {i % 100} with
+    keywords", query "topic keywords", k = 10 and 100; every document matches."""
+    from oracle import bm25_text
+    docs = [f"Document {i} about topic {i % 100} with keywords" for i in range(1000)]
+    ix, chunks = build(trag, docs)
+    ox = bm25_text.TextIndex()
+    for d in docs:
+        ox.add(d)
+    for k in (10, 100):
+        res = ix.search("topic keywords", k)
+        od, os_ = ox.search("topic keywords", k)
+        assert len(res) == k
+        assert [chunks[int(d)].id for d in od] == [r[0] for r in res]
+        assert np.asarray([r[1] for r in res], dtype=np.float32).tobytes() == os_.tobytes()

@@ -519,3 +519,20 @@ def test_large_k_returns_every_row_sorted(trag, oracle, metric):
     rows, scores = store.search_rows(q, 10)          # the usual path still works afterwards
     er, es = oracle.search(corpus, q, 10, metric, dead=dead)
     assert_same_ranking(rows, scores, er, es, "after large k")
+
+
+def test_config1_mock_embedder_corpus(trag, oracle):
+    """BASELINE config 1 with the reference's own generator: MockEmbedder(384) vectors of
+    10k texts, one query, top-10 (benches/retrieval.rs shape, src/embed.rs:124-155 inputs)."""
+    e = trag.MockEmbedder.new(384)
+    n = 10_000
+    corpus = np.stack(e.embed_batch([f"document {i}" for i in range(n)]))
+    store = trag.VectorStore.with_dimension(384)
+    store.insert_rows(corpus)
+    for text in ("document 4242", "a question nobody indexed"):
+        q = e.embed_query(text)
+        rows, scores = store.search_rows(q, 10)
+        er, es = oracle.search(corpus, q, 10, 0)
+        assert rows.tolist() == er.tolist() and scores.tobytes() == es.tobytes()
+    rows, scores = store.search_rows(e.embed_query("document 4242"), 1)
+    assert rows[0] == 4242 and abs(scores[0] - 1.0) < 1e-5

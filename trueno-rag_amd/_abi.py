@@ -90,6 +90,7 @@ SIGNATURES = {
     "trag_bm25_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                            _u32p]),
     "trag_bm25_stats": (C.c_int, [_H, _u64p, _u64p]),
+    "trag_mock_embed": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, C.c_int, _fp]),
     "trag_last_error": (C.c_char_p, []),
     "trag_version": (C.c_char_p, []),
 }
