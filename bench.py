@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 matrix cores")
-    ap.add_argument("--batch", type=int, default=1, help="queries per step (>= 8: matrix-core path)")
+    ap.add_argument("--batch", type=int, default=1, help="queries per step (2..8: one multi-query exact pass; above: matrix-core path)")
     ap.add_argument("--sparse-vocab", type=int, default=50000)
     ap.add_argument("--sparse-tokens", type=int, default=64)
     ap.add_argument("--sparse-terms", type=int, default=8)

@@ -378,7 +378,8 @@ MFMA = 3
 
 
 @pytest.mark.parametrize("metric", [0, 2])
-@pytest.mark.parametrize("n,d,B", [(50_000, 768, 40), (33_333, 384, 130), (20_000, 128, 300)])
+@pytest.mark.parametrize("n,d,B", [(50_000, 768, 40), (33_333, 384, 130), (20_000, 128, 300), (30_000, 256, 9),
+                                   (25_001, 384, 32), (20_000, 64, 64)])
 def test_batch_mfma_parity(trag, oracle, n, d, B, metric):
     rng = np.random.default_rng(n + d + B)
     corpus = unit_rows(rng, n, d) if metric == 0 else rng.standard_normal((n, d)).astype(np.float32)
@@ -405,19 +406,24 @@ def test_batch_mfma_parity(trag, oracle, n, d, B, metric):
     assert st["fallbacks"] <= 2
 
 
-def test_batch_auto_mode_uses_mfma_from_8_queries(trag, oracle):
+def test_batch_auto_mode_uses_mfma_above_8_queries(trag, oracle):
     n, d = 30_000, 384
     store = make_store(trag, d, 0, 0, reserve=n)
     store.fill_synthetic(n, 77)
     corpus = store.read_rows(0, n)
-    Q = oracle.synth_rows(78, 0, 9, d)
+    Q = oracle.synth_rows(78, 0, 17, d)
     rows, scores, cnt = store.search_batch_rows(Q, 10)
     assert store.last_stats()["mode_used"] == MFMA
-    for b in range(9):
+    for b in range(17):
         er, es = oracle.search(corpus, Q[b], 10, 0)
         assert_same_ranking(rows[b], scores[b], er, es, f"auto batch {b}")
-    rows, scores, cnt = store.search_batch_rows(Q[:3], 10)
+    rows, scores, cnt = store.search_batch_rows(Q[:9], 10)
+    assert store.last_stats()["mode_used"] == MFMA
+    rows, scores, cnt = store.search_batch_rows(Q[:8], 10)
     assert store.last_stats()["mode_used"] == EXACT
+    for b in range(8):
+        er, es = oracle.search(corpus, Q[b], 10, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"auto multi {b}")
 
 
 def test_batch_euclidean_falls_back_to_exact_scans(trag, oracle):
@@ -536,3 +542,67 @@ def test_config1_mock_embedder_corpus(trag, oracle):
         assert rows.tolist() == er.tolist() and scores.tobytes() == es.tobytes()
     rows, scores = store.search_rows(e.embed_query("document 4242"), 1)
     assert rows[0] == 4242 and abs(scores[0] - 1.0) < 1e-5
+
+
+# ---------------- multi-query exact scan (2..7 queries share corpus passes) ----------------
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,B", [(5000, 384, 2), (5000, 384, 3), (20_000, 128, 4), (20_000, 100, 5),
+                                   (7777, 768, 7), (300, 36, 6), (64, 4, 2)])
+def test_multi_query_exact_scan(trag, oracle, metric, n, d, B):
+    rng = np.random.default_rng(n + d + B + metric)
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[0] = corpus[n // 2]                      # an exact hit
+    store = make_store(trag, d, metric, EXACT)
+    store.insert_rows(corpus)
+    dead = np.zeros(n, dtype=np.uint8)
+    for r in (0, n // 2 + 1, n - 1):
+        store.remove_row(r)
+        dead[r] = 1
+    for k in (1, 10, 50):
+        rows, scores, cnt = store.search_batch_rows(Q, k)
+        for b in range(B):
+            er, es = oracle.search(corpus, Q[b], k, metric, dead=dead)
+            assert cnt[b] == len(er)
+            assert_same_ranking(rows[b][:cnt[b]], scores[b][:cnt[b]], er, es, f"multi query {b} k={k}")
+    assert store.last_stats()["fallbacks"] == 0
+
+
+def test_multi_query_with_tie_groups_and_zero_query(trag, oracle):
+    # 9000 identical rows force the multi-level select for the queries that hit them
+    n, d = 12_000, 64
+    rng = np.random.default_rng(1)
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    corpus[1000:10_000] = corpus[1000]
+    Q = rng.standard_normal((4, d)).astype(np.float32)
+    Q[1] = corpus[1000]
+    Q[2] = 0.0                                  # zero query: every cosine is 0.0
+    store = make_store(trag, d, 0, EXACT)
+    store.insert_rows(corpus)
+    for _ in range(2):                          # the second call runs with the learned select plan
+        rows, scores, cnt = store.search_batch_rows(Q, 10)
+        for b in range(4):
+            er, es = oracle.search(corpus, Q[b], 10, 0)
+            assert_same_ranking(rows[b], scores[b], er, es, f"multi tie query {b}")
+
+
+def test_multi_query_device_entry(trag, oracle):
+    import torch
+    n, d, B, k = 40_000, 384, 7, 10
+    store = make_store(trag, d, 0, EXACT, reserve=n)
+    store.fill_synthetic(n, 5)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(6, 0, B, d)
+    dq = torch.from_numpy(Q).cuda()
+    o_rows = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+    o_scores = torch.zeros((B, k), dtype=torch.float32, device="cuda")
+    o_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    o_st = torch.full((B,), 9, dtype=torch.int32, device="cuda")
+    store.search_device(dq.data_ptr(), B, k, o_rows.data_ptr(), o_scores.data_ptr(), o_n.data_ptr(),
+                        o_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert o_st.tolist() == [0] * B and o_n.tolist() == [k] * B
+    for b in range(B):
+        er, es = oracle.search(corpus, Q[b], k, 0)
+        assert_same_ranking(o_rows[b].cpu().numpy().astype(np.uint32), o_scores[b].cpu().numpy(), er, es, f"dev {b}")

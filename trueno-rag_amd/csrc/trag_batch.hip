@@ -15,8 +15,6 @@ namespace trag {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BT_M = 128;        // queries per workgroup tile
-constexpr int BT_N = 128;        // corpus rows per workgroup tile
 constexpr int BT_KMIN = 32;      // dimensions must be a multiple of this
 
 // prep for a block of queries: one workgroup per query computes ||q|| in the
@@ -69,8 +67,12 @@ prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict
 }
 
 // ---------------------------------------------------------------------------
-// GEMM scan. Workgroup tile 128 queries x 128 rows, 4 waves as 2 x 2, each
-// wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (4 x 16 accumulator registers).
+// GEMM scan. Four waves per workgroup, arranged WGM (queries) x 4/WGM (rows);
+// each wave owns TM x 2 MFMA tiles of 32 x 32, i.e. 32*TM queries x 64 rows.
+//   <TM 2, WGM 2>: workgroup tile 128 queries x 128 rows (large batches, MFMA-bound)
+//   <TM 2, WGM 1>:                 64 queries x 256 rows
+//   <TM 1, WGM 1>:                 32 queries x 256 rows (few queries: the pass
+//                  is then bound by the corpus read, not by padded tile flops)
 // MFMA roles: A = queries (tile rows), B = corpus rows (tile columns), so an
 // accumulator register holds one query for 32 consecutive corpus rows across
 // the lanes and the key stores are 128-byte runs.
@@ -81,7 +83,7 @@ prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict
 // reads its 16 operands as four contiguous ds_read_b128.
 // METRIC: 0 cosine, 2 dot product.
 // ---------------------------------------------------------------------------
-template <int METRIC, int BT_K /* k-step staged through LDS */>
+template <int METRIC, int BT_K /* k-step staged through LDS */, int TM, int WGM>
 __global__ void __launch_bounds__(256)
 gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpad,
                  const float* __restrict__ norm2, const uint32_t* __restrict__ dead,
@@ -89,7 +91,11 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
                  const SearchCtl* __restrict__ ctls, uint32_t* __restrict__ keys,
                  size_t keys_stride, uint32_t* __restrict__ tmax, size_t tmax_stride) {
     constexpr int BT_LD = BT_K + 4;  // padded LDS row stride (floats): conflict-free b128 reads
-    constexpr int NLD = BT_K / 8;    // 16-byte loads per thread per operand tile (256 threads)
+    constexpr int WGN = 4 / WGM;
+    constexpr int BT_M = 32 * TM * WGM;  // queries per workgroup tile
+    constexpr int BT_N = 64 * WGN;       // corpus rows per workgroup tile
+    constexpr int NLA = BT_M * BT_K / 4 / 256;  // 16-byte loads per thread for the query tile
+    constexpr int NLB = BT_N * BT_K / 4 / 256;  // ... for the corpus tile
     constexpr int CPR = BT_K / 4;    // float4 columns per tile row
     constexpr int RPP = 256 / CPR;   // rows covered by one pass of the 256 threads
     constexpr int KH = BT_K / 2;     // k-values per lane half
@@ -97,7 +103,7 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
     __shared__ __attribute__((aligned(16))) float Bs_[1][BT_N * BT_LD];
     __shared__ float na_s[BT_M];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WGN, wn = wid % WGN;
 
     // Workgroups that share a corpus tile (different query tiles) get ids that
     // are equal mod 8 and adjacent in dispatch order, so that the second read
@@ -106,32 +112,32 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
     const uint32_t xcd = b & 7u, i8 = b >> 3;
     const uint32_t qt = i8 % q_tiles;
     const uint32_t nt = (i8 / q_tiles) * 8u + xcd;
-    const uint32_t n_tiles128 = (n_rows + BT_N - 1) / BT_N;
-    if (nt >= n_tiles128) return;
+    const uint32_t n_row_tiles = (n_rows + BT_N - 1) / BT_N;
+    if (nt >= n_row_tiles) return;
     const uint32_t q0 = qt * BT_M, n0 = nt * BT_N;
 
     if (tid < BT_M) na_s[tid] = (q0 + tid < n_queries) ? ctls[q0 + tid].na : 0.0f;
 
     // staging map: thread -> (row = tid/CPR + RPP*i, float4 column = tid%CPR)
     const int srow = tid / CPR, scol = tid % CPR;
-    const float* aptr[NLD];
-    const float* bptr[NLD];
+    const float* aptr[NLA];
+    const float* bptr[NLB];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        aptr[i] = Qpad + (size_t)(q0 + srow + RPP * i) * d + scol * 4;
+    for (int i = 0; i < NLA; ++i) aptr[i] = Qpad + (size_t)(q0 + srow + RPP * i) * d + scol * 4;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
         const uint32_t r = min(n0 + (uint32_t)(srow + RPP * i), n_rows - 1u);
         bptr[i] = corpus + (size_t)r * d + scol * 4;
     }
-    v4f ra[NLD], rb[NLD];
+    v4f ra[NLA], rb[NLB];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        ra[i] = *reinterpret_cast<const v4f*>(aptr[i]);
-        rb[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i]));
-    }
+    for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const v4f*>(aptr[i]);
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) rb[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i]));
 
-    v16f acc[2][2];
+    v16f acc[TM][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -141,30 +147,31 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
     const uint32_t nk = d / BT_K;
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
+        for (int i = 0; i < NLA; ++i)
             *reinterpret_cast<v4f*>(&As_[buf][(srow + RPP * i) * BT_LD + scol * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
             *reinterpret_cast<v4f*>(&Bs_[buf][(srow + RPP * i) * BT_LD + scol * 4]) = rb[i];
-        }
     };
     auto prefetch = [&](uint32_t kt) {
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            ra[i] = *reinterpret_cast<const v4f*>(aptr[i] + (size_t)kt * BT_K);
+        for (int i = 0; i < NLA; ++i) ra[i] = *reinterpret_cast<const v4f*>(aptr[i] + (size_t)kt * BT_K);
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
             rb[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i] + (size_t)kt * BT_K));
-        }
     };
     auto compute = [&](int buf) {
         const float* As = As_[buf];
         const float* Bs = Bs_[buf];
 #pragma unroll
         for (int kk = 0; kk < KH / 16; ++kk) {  // 16 MFMA k-slots per pass
-            v4f fa[2][4], fb[2][4];
+            v4f fa[TM][4], fb[2][4];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < TM; ++m)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     fa[m][j] = *reinterpret_cast<const v4f*>(
-                        &As[(wm * 64 + m * 32 + frow) * BT_LD + fk + kk * 16 + j * 4]);
+                        &As[(wm * 32 * TM + m * 32 + frow) * BT_LD + fk + kk * 16 + j * 4]);
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -176,7 +183,7 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < TM; ++m)
 #pragma unroll
                         for (int n = 0; n < 2; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[m][j][e], fb[n][j][e],
@@ -215,10 +222,10 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
     }
     const uint32_t tile64 = (n0 + wn * 64) >> 6;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < TM; ++m) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qi = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int qi = wm * 32 * TM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const uint32_t q = q0 + qi;
             const float na = na_s[qi];
             uint32_t kmax = 0u;
@@ -351,23 +358,33 @@ bool batch_supports(uint32_t dim, uint32_t metric) {
 hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a,
                              const float* d_norm2, const BatchScratch& s, uint32_t need, uint32_t k,
                              const float* d_vmax_sq, hipStream_t st) {
+    // query-tile height by batch size: a short batch must not pay for a 128-query tile
+    const int variant = n_queries <= 32 ? 0 : (n_queries <= 64 ? 1 : 2);
+    const uint32_t BT_M = variant == 0 ? 32 : (variant == 1 ? 64 : 128);
+    const uint32_t BT_N = variant == 2 ? 128 : 256;
     const uint32_t q_tiles = (n_queries + BT_M - 1) / BT_M;
     const uint32_t padded = q_tiles * BT_M;
     hipLaunchKernelGGL(pad_queries_kernel, dim3(std::min<uint32_t>(1024, (padded * a.dim + 255) / 256)),
                        dim3(256), 0, st, d_Q, n_queries, padded, a.dim, s.qpad);
     hipLaunchKernelGGL(prep_batch_kernel, dim3(n_queries), dim3(256), 0, st, d_Q, a.dim, s.ctls, need,
                        k, d_vmax_sq);
-    const uint32_t n_tiles128 = (a.n_rows + BT_N - 1) / BT_N;
-    const uint32_t groups = (n_tiles128 + 7) / 8;  // corpus tiles in groups of 8 (one per XCD slot)
+    const uint32_t n_row_tiles = (a.n_rows + BT_N - 1) / BT_N;
+    const uint32_t groups = (n_row_tiles + 7) / 8;  // corpus tiles in groups of 8 (one per XCD slot)
     const uint32_t grid = groups * q_tiles * 8;
-    if (a.metric == TRAG_COSINE)
-        hipLaunchKernelGGL((gemm_scan_kernel<0, 32>), dim3(grid), dim3(256), 0, st, a.corpus, s.qpad,
-                           d_norm2, a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys,
-                           s.keys_stride, s.tmax, s.tmax_stride);
-    else
-        hipLaunchKernelGGL((gemm_scan_kernel<2, 32>), dim3(grid), dim3(256), 0, st, a.corpus, s.qpad,
-                           d_norm2, a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys,
-                           s.keys_stride, s.tmax, s.tmax_stride);
+#define TRAG_LAUNCH_GEMM(METRIC, TM, WGM)                                                              \
+    hipLaunchKernelGGL((gemm_scan_kernel<METRIC, 32, TM, WGM>), dim3(grid), dim3(256), 0, st, a.corpus, \
+                       s.qpad, d_norm2, a.dead, a.n_rows, a.dim, n_queries, q_tiles, s.ctls, s.keys,    \
+                       s.keys_stride, s.tmax, s.tmax_stride)
+    if (a.metric == TRAG_COSINE) {
+        if (variant == 0) TRAG_LAUNCH_GEMM(0, 1, 1);
+        else if (variant == 1) TRAG_LAUNCH_GEMM(0, 2, 1);
+        else TRAG_LAUNCH_GEMM(0, 2, 2);
+    } else {
+        if (variant == 0) TRAG_LAUNCH_GEMM(2, 1, 1);
+        else if (variant == 1) TRAG_LAUNCH_GEMM(2, 2, 1);
+        else TRAG_LAUNCH_GEMM(2, 2, 2);
+    }
+#undef TRAG_LAUNCH_GEMM
     const uint32_t n_tiles64 = (a.n_rows + 63) / 64;
     hipLaunchKernelGGL(tau_select_kernel, dim3(n_queries), dim3(256), 0, st, s.tmax, s.tmax_stride,
                        n_tiles64, s.ctls);

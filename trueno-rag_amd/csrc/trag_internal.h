@@ -71,6 +71,25 @@ struct BatchScratch {
 constexpr uint32_t ST_OVERFLOW = 2;     // more candidates than the final sort holds: repeat exactly
 constexpr uint32_t BATCH_QUERIES = 256; // queries processed per batched pass
 
+// Queries a multi-query exact scan handles in one corpus pass.
+constexpr uint32_t MULTI_QUERIES = 8;
+// LDS budget of a multi-query pass (of the CU's 160 KB) and its static part: 4 wave tiles of
+// 64 x 36 floats, one coarse histogram and one norm per query; the rest holds the queries.
+constexpr uint64_t MULTI_LDS_TOTAL = 158 * 1024;
+constexpr uint64_t multi_static_lds(uint32_t nq) {
+    return 4ull * 64 * 36 * 4 + (uint64_t)nq * HIST_BINS * 4 + (uint64_t)nq * 4 + 64;
+}
+
+// Distance between consecutive queries' scratch in a multi-query scan: query j's
+// control block + histograms start j * zero_bytes BYTES behind the first one's,
+// its keys / tile maxima / wave maxima j * keys / tmax / wmax ELEMENTS behind.
+struct MultiStride {
+    size_t zero_bytes = 0;
+    size_t keys = 0;
+    size_t tmax = 0;
+    size_t wmax = 0;
+};
+
 struct ScanArgs {
     const float* corpus;
     const uint32_t* dead;  // tombstone bitmap, 1 bit per row
@@ -88,10 +107,18 @@ hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch&
                              uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st);
 hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
                               uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st);
+// n_queries > 1: one workgroup per query of a multi-query scan (scratch strided by *ms, the
+// queries d apart, outputs out_stride entries apart)
 hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
                                uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
                                uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
-                               uint32_t* d_status, hipStream_t st);
+                               uint32_t* d_status, hipStream_t st, uint32_t n_queries = 1,
+                               const MultiStride* ms = nullptr, uint32_t out_stride = 0);
+// exact scan of 2..MULTI_QUERIES queries (rows of d_q) in one corpus pass; s is query 0's scratch
+uint32_t multi_group_limit(uint32_t dim);
+hipError_t launch_scan_exact_multi(const float* d_q, uint32_t n_queries, const ScanArgs& a,
+                                   const Scratch& s, const MultiStride& ms, uint32_t need, uint32_t k,
+                                   const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st);
 bool stream_supports_dim(uint32_t dim);
 hipError_t launch_select(const ScanArgs& a, const Scratch& s, hipStream_t st);
 hipError_t launch_reset_ctl(const Scratch& s, hipStream_t st);

@@ -5,6 +5,8 @@
 // below is two roundings, exactly as the reference's scalar f32 loops
 // (src/index.rs:440-462 of the reference). Fused multiply-adds appear only
 // where written as __builtin_fmaf.
+#include <algorithm>
+
 #include "trag_device.h"
 #include "trag_internal.h"
 #include "trag_scan_common.h"
@@ -175,6 +177,155 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
     for (int i = tid; i < (int)HIST_BINS; i += WPB * 64) {
         const uint32_t h = lhist[i];
         if (h) atomicAdd(&hist[i], h);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Exact scan of NQ queries in one corpus pass (d % 4 == 0). Same staging as
+// above; every lane keeps one accumulator per query for its row, so each
+// (row, query) sum still runs left to right in the reference's order, and the
+// row's own sum of squares (cosine) is computed once for all queries. The
+// pass is still bound by the HBM read of the corpus: NQ queries for the bytes
+// of one. Query j's keys / maxima / histogram / control block live at
+// j * stride behind the base pointers (MultiStride).
+// ---------------------------------------------------------------------------
+template <int METRIC, int NQ>
+__global__ void __launch_bounds__(256)
+scan_exact_multi_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
+                        const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
+                        uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
+                        SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
+                        uint32_t* __restrict__ tmax, uint32_t* __restrict__ wmax,
+                        uint32_t* __restrict__ hist, MultiStride ms) {
+    constexpr int EX_CW = 32, EX_STRIDE = EX_CW + 4, LPR = EX_CW / 4, RPL = 64 / LPR, NLD = 64 / RPL, WPB = 4;
+    __shared__ __attribute__((aligned(16))) float tiles[WPB][64 * EX_STRIDE];
+    __shared__ uint32_t lhist[NQ][HIST_BINS];
+    __shared__ float na_sh[NQ];
+    // the NQ queries, contiguous (NQ * d floats, dynamic): every lane reads them with
+    // same-address (broadcast) 16-byte LDS loads, which keeps the vector-memory queue
+    // for the corpus prefetch alone and the scalar registers out of the picture
+    extern __shared__ __attribute__((aligned(16))) float qsh[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < NQ * (int)HIST_BINS; i += WPB * 64) (&lhist[0][0])[i] = 0u;
+
+    float* tile = tiles[wid];
+    const uint32_t n_tiles = (n_rows + 63u) >> 6;
+    const uint32_t n_waves = gridDim.x * (uint32_t)WPB;
+    const uint32_t d4 = d >> 2;
+    const uint32_t n_chunks = (d + EX_CW - 1) / EX_CW;
+    const int lrow = lane / LPR, lcol = lane % LPR;
+
+    uint32_t t = blockIdx.x * (uint32_t)WPB + wid;
+    v4f pre[NLD];
+    auto issue = [&](uint32_t tt, uint32_t c) {
+        const uint32_t col4 = min(c * (uint32_t)LPR + (uint32_t)lcol, d4 - 1u);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const uint32_t r = min(tt * 64u + (uint32_t)(i * RPL + lrow), n_rows - 1u);
+            pre[i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(corpus + (size_t)r * d) + col4);
+        }
+    };
+    if (t < n_tiles) issue(t, 0);
+    for (uint32_t i = tid; i < (uint32_t)NQ * d4; i += WPB * 64)
+        reinterpret_cast<v4f*>(qsh)[i] = reinterpret_cast<const v4f*>(q)[i];
+    // ||q_j|| while the first loads are in flight: wave w takes queries w, w + 4, ...
+    for (int j = wid; j < NQ; j += WPB) {
+        if (METRIC == 0 || blockIdx.x == 0) {
+            const float nsq = query_norm_sq_wave(q + (size_t)j * d, d, lane);
+            if (lane == 0) {
+                na_sh[j] = sqrtf(nsq);
+                if (blockIdx.x == 0)
+                    publish_ctl(reinterpret_cast<SearchCtl*>(reinterpret_cast<char*>(ctl) + j * ms.zero_bytes),
+                                nsq, need, k, vmax_sq, n_waves);
+            }
+        }
+    }
+    __syncthreads();
+    float na[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) na[j] = METRIC == 0 ? na_sh[j] : 0.0f;
+    uint32_t wave_best[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) wave_best[j] = 0u;
+    const uint32_t wave_id = blockIdx.x * (uint32_t)WPB + wid;
+    while (t < n_tiles) {
+        float acc0[NQ], acc1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) acc0[j] = 0.0f;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                *reinterpret_cast<v4f*>(&tile[(i * RPL + lrow) * EX_STRIDE + lcol * 4]) = pre[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (c + 1 < n_chunks) issue(t, c + 1);
+            else if (t + n_waves < n_tiles) issue(t + n_waves, 0);
+            const float* qc = qsh + c * EX_CW;
+            const float* myrow = tile + lane * EX_STRIDE;
+            const uint32_t len = min((uint32_t)EX_CW, d - c * EX_CW);
+            // four consecutive columns of the row against the same columns of every query
+            auto quad = [&](uint32_t col) {
+                const v4f x = *reinterpret_cast<const v4f*>(myrow + col);
+                v4f qq[NQ];
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) qq[j] = *reinterpret_cast<const v4f*>(qc + (size_t)j * d + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xe = x[e];
+                    if (METRIC == 0) {
+                        const float p2 = xe * xe;
+                        acc1 = acc1 + p2;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        const float qv = qq[j][e];
+                        if (METRIC == 1) {
+                            const float tdiff = qv - xe;
+                            const float p = tdiff * tdiff;
+                            acc0[j] = acc0[j] + p;
+                        } else {
+                            const float p = qv * xe;
+                            acc0[j] = acc0[j] + p;
+                        }
+                    }
+                }
+            };
+            if (len == EX_CW) {
+#pragma unroll
+                for (int j4 = 0; j4 < EX_CW / 4; ++j4) quad(j4 * 4);
+            } else {
+                for (uint32_t j4 = 0; j4 < len / 4; ++j4) quad(j4 * 4);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint32_t row = t * 64u + lane;
+        const bool live = row < n_rows && !row_is_dead(dead, row);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            uint32_t key = 0u;
+            if (live) {
+                key = score_key(finish_score<METRIC>(acc0[j], acc1, na[j]));
+                atomicAdd(&lhist[j][key >> 21], 1u);
+            }
+            if (row < n_rows) keys[(size_t)j * ms.keys + row] = key;
+            const uint32_t tm = wave_max_u32(key);
+            if (lane == 0) tmax[(size_t)j * ms.tmax + t] = tm;
+            wave_best[j] = tm > wave_best[j] ? tm : wave_best[j];
+        }
+        t += n_waves;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) wmax[(size_t)j * ms.wmax + wave_id] = wave_best[j];
+    }
+    __syncthreads();
+    for (int i = tid; i < NQ * (int)HIST_BINS; i += WPB * 64) {
+        const uint32_t h = (&lhist[0][0])[i];
+        if (h) {
+            const int j = i / (int)HIST_BINS, bin = i % (int)HIST_BINS;
+            atomicAdd(reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + j * ms.zero_bytes) + bin, h);
+        }
     }
 }
 
@@ -560,7 +711,21 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
                     const uint32_t* __restrict__ wmax, uint32_t* __restrict__ out_rows,
                     float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
-                    uint32_t* __restrict__ out_status) {
+                    uint32_t* __restrict__ out_status, MultiStride ms, uint32_t out_stride) {
+    // one workgroup per query of a multi-query scan (blockIdx.x = query; strides 0 for one query)
+    {
+        const size_t b = blockIdx.x;
+        q += b * d;
+        ctl = reinterpret_cast<SearchCtl*>(reinterpret_cast<char*>(ctl) + b * ms.zero_bytes);
+        hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + b * ms.zero_bytes);
+        keys += b * ms.keys;
+        tmax += b * ms.tmax;
+        wmax += b * ms.wmax;
+        out_rows += b * out_stride;
+        out_scores += b * out_stride;
+        out_n += b;
+        if (out_status) out_status += b;
+    }
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t hit[CAND_CAP];
     __shared__ uint32_t sh[24];
@@ -1064,31 +1229,94 @@ template <int METRIC>
 static void select_final_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
                                   uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
                                   uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
-                                  uint32_t* d_status, hipStream_t st) {
+                                  uint32_t* d_status, uint32_t n_queries, const MultiStride& ms,
+                                  uint32_t out_stride, hipStream_t st) {
     if (rescore)
-        hipLaunchKernelGGL((select_final_kernel<METRIC, true>), dim3(1), dim3(1024), 0, st, a.corpus,
+        hipLaunchKernelGGL((select_final_kernel<METRIC, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus,
                            d_q, a.n_rows, a.dim, live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax,
-                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status);
+                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride);
     else
-        hipLaunchKernelGGL((select_final_kernel<METRIC, false>), dim3(1), dim3(1024), 0, st, a.corpus,
+        hipLaunchKernelGGL((select_final_kernel<METRIC, false>), dim3(n_queries), dim3(1024), 0, st, a.corpus,
                            d_q, a.n_rows, a.dim, live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax,
-                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status);
+                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride);
 }
 
 hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
                                uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
                                uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
-                               uint32_t* d_status, hipStream_t st) {
+                               uint32_t* d_status, hipStream_t st, uint32_t n_queries,
+                               const MultiStride* ms, uint32_t out_stride) {
+    const MultiStride m = ms ? *ms : MultiStride{};
     switch (a.metric) {
     case TRAG_COSINE:
-        select_final_dispatch<0>(d_q, a, s, rescore, live, need, k, n_waves, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        select_final_dispatch<0>(d_q, a, s, rescore, live, need, k, n_waves, d_out_rows, d_out_scores, d_out_n, d_status, n_queries, m, out_stride, st);
         break;
     case TRAG_EUCLIDEAN:
-        select_final_dispatch<1>(d_q, a, s, rescore, live, need, k, n_waves, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        select_final_dispatch<1>(d_q, a, s, rescore, live, need, k, n_waves, d_out_rows, d_out_scores, d_out_n, d_status, n_queries, m, out_stride, st);
         break;
     default:
-        select_final_dispatch<2>(d_q, a, s, rescore, live, need, k, n_waves, d_out_rows, d_out_scores, d_out_n, d_status, st);
+        select_final_dispatch<2>(d_q, a, s, rescore, live, need, k, n_waves, d_out_rows, d_out_scores, d_out_n, d_status, n_queries, m, out_stride, st);
         break;
+    }
+    return hipGetLastError();
+}
+
+// Queries one multi-query pass can take at this dimension (their LDS copy must fit), 0 or 1 = none.
+uint32_t multi_group_limit(uint32_t dim) {
+    if (dim & 3u) return 0;
+    uint32_t nq = MULTI_QUERIES;
+    while (nq >= 2 && multi_static_lds(nq) + (uint64_t)nq * dim * sizeof(float) > MULTI_LDS_TOTAL) --nq;
+    return nq;
+}
+
+template <int METRIC>
+static uint32_t scan_multi_dispatch(const float* d_q, uint32_t nq, const ScanArgs& a, const Scratch& s,
+                                    const MultiStride& ms, uint32_t need, uint32_t k,
+                                    const float* d_vmax_sq, hipStream_t st) {
+    const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    const uint32_t grid = grid_for(n_tiles, 4, (uint32_t)n_cu);
+    const size_t q_bytes = (size_t)nq * a.dim * sizeof(float);
+#define TRAG_LAUNCH_MULTI(NQ)                                                                              \
+    do {                                                                                                   \
+        static bool attr_set = false;                                                                      \
+        if (!attr_set) {                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_exact_multi_kernel<METRIC, NQ>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,                          \
+                                      (int)(MULTI_LDS_TOTAL - multi_static_lds(NQ)));                      \
+            attr_set = true;                                                                               \
+        }                                                                                                  \
+        hipLaunchKernelGGL((scan_exact_multi_kernel<METRIC, NQ>), dim3(grid), dim3(256), q_bytes, st,      \
+                           a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,      \
+                           s.tmax, s.wmax, s.hist, ms);                                                    \
+    } while (0)
+    switch (nq) {
+    case 2: TRAG_LAUNCH_MULTI(2); break;
+    case 3: TRAG_LAUNCH_MULTI(3); break;
+    case 4: TRAG_LAUNCH_MULTI(4); break;
+    case 5: TRAG_LAUNCH_MULTI(5); break;
+    case 6: TRAG_LAUNCH_MULTI(6); break;
+    case 7: TRAG_LAUNCH_MULTI(7); break;
+    default: TRAG_LAUNCH_MULTI(8); break;
+    }
+#undef TRAG_LAUNCH_MULTI
+    return grid * 4u;
+}
+
+hipError_t launch_scan_exact_multi(const float* d_q, uint32_t n_queries, const ScanArgs& a,
+                                   const Scratch& s, const MultiStride& ms, uint32_t need, uint32_t k,
+                                   const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st) {
+    if (n_queries < 2 || n_queries > multi_group_limit(a.dim)) return hipErrorInvalidValue;
+    switch (a.metric) {
+    case TRAG_COSINE: *n_waves = scan_multi_dispatch<0>(d_q, n_queries, a, s, ms, need, k, d_vmax_sq, st); break;
+    case TRAG_EUCLIDEAN: *n_waves = scan_multi_dispatch<1>(d_q, n_queries, a, s, ms, need, k, d_vmax_sq, st); break;
+    default: *n_waves = scan_multi_dispatch<2>(d_q, n_queries, a, s, ms, need, k, d_vmax_sq, st); break;
     }
     return hipGetLastError();
 }
