@@ -14,9 +14,10 @@ from .sparse import BM25Index  # noqa: F401
 from .embed import MockEmbedder, EmbeddingConfig, EmptyDocument, QueryError  # noqa: F401
 from .persist import PersistedIndex, PersistedChunk, IndexServer  # noqa: F401
 from .fusion import FusionStrategy  # noqa: F401
+from .rerank import LexicalReranker, NoOpReranker  # noqa: F401
 from .retrieve import (DenseRetriever, HybridRetriever, HybridRetrieverConfig,  # noqa: F401
                        RetrievalResult)
 
 __all__ = ["lib", "lib_path", "TragError", "DimensionMismatch", "InvalidConfig", "VectorStore",
            "VectorStoreConfig", "DistanceMetric", "Chunk", "ChunkId", "BM25Index", "MockEmbedder", "EmbeddingConfig", "EmptyDocument", "QueryError", "PersistedIndex", "PersistedChunk", "IndexServer", "FusionStrategy",
-           "DenseRetriever", "HybridRetriever", "HybridRetrieverConfig", "RetrievalResult"]
+           "LexicalReranker", "NoOpReranker", "DenseRetriever", "HybridRetriever", "HybridRetrieverConfig", "RetrievalResult"]
