@@ -54,7 +54,7 @@ typedef enum trag_scan_mode {
     TRAG_SCAN_EXACT = 1,  /* every row scored with the reference's sequential f32 order */
     TRAG_SCAN_STREAM = 2, /* reassociated streaming scan + exact re-score of candidates */
     TRAG_SCAN_MFMA = 3    /* query batches as Q x D^T on the matrix cores + exact re-score
-                             (cosine / dot product, dim % 32 == 0); AUTO picks it above 8 queries;
+                             (dim % 32 == 0); AUTO picks it above 8 queries;
                              2..8 queries share one exact corpus pass */
 } trag_scan_mode;
 

@@ -377,7 +377,7 @@ def test_hybrid_retriever_path(trag, oracle):
 MFMA = 3
 
 
-@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("n,d,B", [(50_000, 768, 40), (33_333, 384, 130), (20_000, 128, 300), (30_000, 256, 9),
                                    (25_001, 384, 32), (20_000, 64, 64)])
 def test_batch_mfma_parity(trag, oracle, n, d, B, metric):
@@ -426,17 +426,34 @@ def test_batch_auto_mode_uses_mfma_above_8_queries(trag, oracle):
         assert_same_ranking(rows[b], scores[b], er, es, f"auto multi {b}")
 
 
-def test_batch_euclidean_falls_back_to_exact_scans(trag, oracle):
+def test_batch_euclidean_on_matrix_cores(trag, oracle):
     n, d, B = 8000, 128, 12
     rng = np.random.default_rng(12)
     corpus = rng.standard_normal((n, d)).astype(np.float32)
+    corpus[100] = corpus[7000]                 # duplicates: distance ties
+    corpus[4000] *= 1e-3                       # a short row
     Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[2] = corpus[100]                         # distance 0 to two rows
+    Q[3] = corpus[55] + np.float32(1e-4)       # a near-duplicate: cancellation in the squared form
     store = make_store(trag, d, 1, 0)
     store.insert_rows(corpus)
     rows, scores, _ = store.search_batch_rows(Q, 10)
+    assert store.last_stats()["mode_used"] == MFMA
     for b in range(B):
         er, es = oracle.search(corpus, Q[b], 10, 1)
         assert_same_ranking(rows[b], scores[b], er, es, f"euclid batch {b}")
+    assert rows[2][:2].tolist() == [100, 7000]
+    # unit-norm rows at 384 dims, a larger corpus: nearest-neighbour gaps are small there
+    n2, d2 = 60_000, 384
+    store2 = make_store(trag, d2, 1, 0, reserve=n2)
+    store2.fill_synthetic(n2, 31)
+    corpus2 = store2.read_rows(0, n2)
+    Q2 = oracle.synth_rows(32, 0, 20, d2)
+    rows, scores, _ = store2.search_batch_rows(Q2, 10)
+    for b in range(20):
+        er, es = oracle.search(corpus2, Q2[b], 10, 1)
+        assert_same_ranking(rows[b], scores[b], er, es, f"euclid unit batch {b}")
+    assert store2.last_stats()["fallbacks"] <= 2
 
 
 # ---------------- cross-shard exchange kernels (one GPU stands in for two shards) ----------------

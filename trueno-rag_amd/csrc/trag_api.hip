@@ -83,6 +83,7 @@ struct trag_store {
     MultiStride mstride{};
     void* m_zero_block = nullptr;
     uint64_t m_keys_cap = 0;
+    const SearchCtl* last_ctl = nullptr;  // control block of the last query enqueued (diagnostics)
     bool full_select = false;      // learned: this corpus needs the multi-level select
     unsigned long long* d_sort = nullptr;  // large-k path: rank keys of every row, padded to 2^m
     unsigned long long sort_cap = 0;
@@ -159,6 +160,7 @@ trag_status ensure_scratch(trag_store* s) {
         s->scratch.tmax = nullptr;
         s->zero_block = nullptr;
         s->keys_cap = 0;
+        s->last_ctl = nullptr;
         const size_t ctl_bytes = 256;  // SearchCtl padded
         static_assert(sizeof(SearchCtl) <= 256, "control block grew");
         s->zero_bytes = ctl_bytes + HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
@@ -185,6 +187,7 @@ trag_status ensure_multi_scratch(trag_store* s) {
     s->mscratch = Scratch{};
     s->m_zero_block = nullptr;
     s->m_keys_cap = 0;
+    s->last_ctl = nullptr;
     MultiStride ms;
     ms.zero_bytes = 256 + HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
     ms.keys = (size_t)s->cap_rows;
@@ -378,9 +381,12 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             HIP_TRY(launch_select_final(q, a, s->mscratch, false, live, need, k_eff, n_waves,
                                         d_out_rows + (size_t)b * k, d_out_scores + (size_t)b * k, d_out_n + b,
                                         d_status ? d_status + b : nullptr, st, group, &s->mstride, k));
+            s->last_ctl = reinterpret_cast<const SearchCtl*>(reinterpret_cast<const char*>(s->mscratch.ctl) +
+                                                             (size_t)(group - 1) * s->mstride.zero_bytes);
             b += group - 1;
             continue;
         }
+        s->last_ctl = s->scratch.ctl;
         if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
         else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -657,7 +663,7 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
         s->stats.refine_levels = 0;
     } else {
         SearchCtl ctl;
-        HIP_TRY(hipMemcpy(&ctl, s->scratch.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&ctl, s->last_ctl ? s->last_ctl : s->scratch.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
         s->stats.candidates = ctl.expect;
         s->stats.refine_levels = ctl.levels;
     }

@@ -81,7 +81,9 @@ prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict
 // The 32 k-values of a staged step are assigned to the 16 MFMAs as
 // k = 16 * (lane >> 5) + s (s = MFMA index), the same for A and B, so each lane
 // reads its 16 operands as four contiguous ds_read_b128.
-// METRIC: 0 cosine, 2 dot product.
+// METRIC: 0 cosine, 2 dot product, 1 Euclidean (keys order the negated squared
+// distance ||q||^2 + ||v||^2 - 2 q.v from the cached norms; the final stage
+// re-scores with the reference's sqrt(sum (x - y)^2) and certifies in squared space).
 // ---------------------------------------------------------------------------
 template <int METRIC, int BT_K /* k-step staged through LDS */, int TM, int WGM>
 __global__ void __launch_bounds__(256)
@@ -116,7 +118,8 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
     if (nt >= n_row_tiles) return;
     const uint32_t q0 = qt * BT_M, n0 = nt * BT_N;
 
-    if (tid < BT_M) na_s[tid] = (q0 + tid < n_queries) ? ctls[q0 + tid].na : 0.0f;
+    if (tid < BT_M)
+        na_s[tid] = (q0 + tid < n_queries) ? (METRIC == 1 ? ctls[q0 + tid].na_sq : ctls[q0 + tid].na) : 0.0f;
 
     // staging map: thread -> (row = tid/CPR + RPP*i, float4 column = tid%CPR)
     const int srow = tid / CPR, scol = tid % CPR;
@@ -204,7 +207,7 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
     // ---- epilogue: scores -> ordered keys, per-(query, 64-row tile) maxima ----
     const int half = lane >> 5;
     uint32_t rows_[2];
-    float inv_nb[2];
+    float inv_nb[2], nb2_[2];
     bool live[2], ok_nb[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -213,12 +216,13 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
         live[n] = row < n_rows && !row_is_dead(dead, row);
         float nb2 = 1.0f;
         ok_nb[n] = true;
-        if (METRIC == 0) {
+        if (METRIC != 2) {
             nb2 = row < n_rows ? norm2[row] : 0.0f;
             // outside this range the error bound of the certification does not hold
             ok_nb[n] = nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY);
         }
         inv_nb[n] = nb2 > 0.0f ? 1.0f / sqrtf(nb2) : 0.0f;
+        nb2_[n] = nb2;
     }
     const uint32_t tile64 = (n0 + wn * 64) >> 6;
 #pragma unroll
@@ -235,6 +239,11 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
                 float s;
                 if (METRIC == 0) {
                     s = (na > 0.0f) ? dot * (inv_nb[n] / na) : 0.0f;
+                    if (!ok_nb[n]) s = INFINITY;
+                } else if (METRIC == 1) {
+                    const float two_dot = 2.0f * dot;
+                    const float sum2 = na + nb2_[n];   // na holds ||q||^2 for this metric
+                    s = -(sum2 - two_dot);
                     if (!ok_nb[n]) s = INFINITY;
                 } else {
                     s = dot;
@@ -352,7 +361,7 @@ pad_queries_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t pad
 }
 
 bool batch_supports(uint32_t dim, uint32_t metric) {
-    return (dim % BT_KMIN) == 0 && (metric == TRAG_COSINE || metric == TRAG_DOT_PRODUCT);
+    return (dim % BT_KMIN) == 0 && metric <= TRAG_DOT_PRODUCT;
 }
 
 hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a,
@@ -379,6 +388,10 @@ hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArg
         if (variant == 0) TRAG_LAUNCH_GEMM(0, 1, 1);
         else if (variant == 1) TRAG_LAUNCH_GEMM(0, 2, 1);
         else TRAG_LAUNCH_GEMM(0, 2, 2);
+    } else if (a.metric == TRAG_EUCLIDEAN) {
+        if (variant == 0) TRAG_LAUNCH_GEMM(1, 1, 1);
+        else if (variant == 1) TRAG_LAUNCH_GEMM(1, 2, 1);
+        else TRAG_LAUNCH_GEMM(1, 2, 2);
     } else {
         if (variant == 0) TRAG_LAUNCH_GEMM(2, 1, 1);
         else if (variant == 1) TRAG_LAUNCH_GEMM(2, 2, 1);

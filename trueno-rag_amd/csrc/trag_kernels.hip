@@ -602,16 +602,29 @@ __device__ float exact_score_row(const float* __restrict__ v, const float* __res
 // most eps, so the exact top-k is final when its last member clears t + eps.
 template <int METRIC>
 __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float na, uint32_t t_key,
-                            float ek) {
+                            float ek, bool sq_keys = false) {
     uint32_t status = ST_OK;
     const float u = 5.9604645e-08f;  // 2^-24
     float eps = (2.0f * (float)d + 64.0f) * u;
     const float vmax = sqrtf(ctl->vmax_sq);
-    if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
-    if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
     // the bound assumes ||q||^2 is a normal number well inside the f32 range
     const float nsq = ctl->na_sq;
     if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f))) status = ST_UNCERTIFIED;
+    if (METRIC == 1 && sq_keys) {
+        // Matrix-core Euclidean pass: keys order -(||q||^2 + ||v||^2 - 2 q.v), an approximation of
+        // the negated SQUARED distance with absolute error <= eps * (||q|| + ||v||)^2. Every row
+        // left behind has approximate squared distance >= T2 = -t; the exact k-th distance
+        // (squared, plus the rounding of the exact path) must stay below T2 minus that error.
+        const float span = na + vmax;
+        const float eps2 = eps * span * span * 1.01f + 1e-30f;
+        const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
+        const float T2 = -t;
+        const float dk2 = ek * ek * (1.0f + eps);
+        if (!(dk2 + eps2 < T2) || !(eps2 < INFINITY)) status = ST_UNCERTIFIED;
+        return status;
+    }
+    if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
+    if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
     const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
     if (!(ek > t + eps) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
     return status;
@@ -638,8 +651,9 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
         out_n += y;
         if (out_status) out_status += y;
     }
-    // use_count: the candidates were gathered against a given threshold and
-    // their number is only known from the append cursor
+    // use_count != 0: the candidates were gathered against a given threshold and
+    // their number is only known from the append cursor; 2: the keys are in the
+    // squared-distance space of the matrix-core Euclidean pass (see certify)
     uint32_t C = use_count ? ctl->cand_count : ctl->expect;
     const bool overflow = C > CAND_CAP;
     if (C > CAND_CAP) C = CAND_CAP;
@@ -685,7 +699,8 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
         *out_n = n_out;
         uint32_t status = ST_OK;
         if (RESCORE && C < live && n_out > 0)
-            status = certify<METRIC>(ctl, d, na, ctl->t_key, key_score((uint32_t)(sk[n_out - 1] >> 32)));
+            status = certify<METRIC>(ctl, d, na, ctl->t_key, key_score((uint32_t)(sk[n_out - 1] >> 32)),
+                                     use_count == 2);
         if (overflow) status = ST_OVERFLOW;
         ctl->levels = ctl->resolved ? ctl->resolved : 3;
         ctl->status = status;
@@ -1380,6 +1395,10 @@ hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanA
         hipLaunchKernelGGL((final_kernel<0, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,
                            a.n_rows, a.dim, live, s.ctls, s.keys, s.cand, d_out_rows, d_out_scores,
                            d_out_n, d_status, s.keys_stride, out_stride, 1);
+    else if (a.metric == TRAG_EUCLIDEAN)
+        hipLaunchKernelGGL((final_kernel<1, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,
+                           a.n_rows, a.dim, live, s.ctls, s.keys, s.cand, d_out_rows, d_out_scores,
+                           d_out_n, d_status, s.keys_stride, out_stride, 2);
     else
         hipLaunchKernelGGL((final_kernel<2, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,
                            a.n_rows, a.dim, live, s.ctls, s.keys, s.cand, d_out_rows, d_out_scores,
