@@ -273,14 +273,14 @@ gemm_scan_kernel(const float* __restrict__ corpus, const float* __restrict__ Qpa
 // One workgroup per query; three radix levels (11 + 11 + 10 bits) over the
 // query's tile maxima with workgroup-local histograms.
 // ---------------------------------------------------------------------------
-__device__ void find_bin256(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
-                            uint32_t* sh);  // defined below (LDS histogram variant)
+__device__ void find_bin_lds(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
+                             uint32_t* sh);  // defined below
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 tau_select_kernel(const uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_t n_tiles,
                   SearchCtl* __restrict__ ctls) {
     __shared__ uint32_t lhist[HIST_BINS];
-    __shared__ uint32_t sh[8];
+    __shared__ uint32_t sh[18];
     const int tid = threadIdx.x;
     const uint32_t* tm = tmax + (size_t)blockIdx.x * tmax_stride;
     SearchCtl* ctl = ctls + blockIdx.x;
@@ -293,33 +293,44 @@ tau_select_kernel(const uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_
     const int shifts[3] = {21, 10, 0};
     const uint32_t widths[3] = {11, 11, 10};
     for (int level = 0; level < 3; ++level) {
-        for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
+        for (int i = tid; i < (int)HIST_BINS; i += 1024) lhist[i] = 0u;
         __syncthreads();
         const uint32_t mshift = 32u - prefix_bits;
-        for (uint32_t i = tid; i < n_tiles; i += 256) {
-            const uint32_t v = tm[i];
-            const bool match = prefix_bits == 0 || (v >> mshift) == prefix;
-            if (match) atomicAdd(&lhist[(v >> shifts[level]) & ((1u << widths[level]) - 1u)], 1u);
+        const uint32_t shift = (uint32_t)shifts[level], mask = (1u << widths[level]) - 1u;
+        // four independent loads in flight per thread: the pass is latency-bound
+        for (uint32_t i0 = 0; i0 < n_tiles; i0 += 4096u) {
+            uint32_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i = i0 + (uint32_t)j * 1024u + (uint32_t)tid;
+                v[j] = i < n_tiles ? tm[i] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i = i0 + (uint32_t)j * 1024u + (uint32_t)tid;
+                const bool match = prefix_bits == 0 || (v[j] >> mshift) == prefix;
+                if (i < n_tiles && match) atomicAdd(&lhist[(v[j] >> shift) & mask], 1u);
+            }
         }
         __syncthreads();
         uint32_t bin, above;
-        find_bin256(lhist, need, bin, above, sh);
+        find_bin_lds(lhist, need, bin, above, sh);
         need -= above;
         prefix = (prefix << widths[level]) | bin;
         prefix_bits += widths[level];
-        __syncthreads();
     }
     if (tid == 0) ctl->t_key = prefix > 1u ? prefix : 1u;
 }
 
-// find_bin over a histogram in LDS (same contract as the global-memory one).
-__device__ void find_bin256(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
-                            uint32_t* sh) {
+// find_bin over a histogram in LDS, called by all 1024 threads of the workgroup:
+// the highest bin whose suffix count reaches `need`, and the count strictly above
+// it. sh: 18 words (16 wave totals, then bin and count).
+__device__ void find_bin_lds(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
+                             uint32_t* sh) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int top = (int)HIST_BINS - 1 - 8 * t;
-    uint32_t h[8], sum = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { h[i] = hist[top - i]; sum += h[i]; }
+    const int top = (int)HIST_BINS - 1 - 2 * t;  // thread t owns bins top and top - 1
+    const uint32_t h0 = hist[top], h1 = hist[top - 1];
+    const uint32_t sum = h0 + h1;
     uint32_t incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -327,25 +338,24 @@ __device__ void find_bin256(const uint32_t* hist, uint32_t need, uint32_t& bin, 
         if (lane >= o) incl += v;
     }
     if (lane == 63) sh[w] = incl;
-    if (t == 0) { sh[4] = 0; sh[5] = 0; }
+    if (t == 0) { sh[16] = 0; sh[17] = 0; }
     __syncthreads();
-    uint32_t base = 0;
-    for (int i = 0; i < w; ++i) base += sh[i];
-    const uint32_t total = sh[0] + sh[1] + sh[2] + sh[3];
+    uint32_t base = 0, total = 0;
+    for (int i = 0; i < 16; ++i) {
+        if (i < w) base += sh[i];
+        total += sh[i];
+    }
     incl += base;
     const uint32_t excl = incl - sum;
     if (need > total) need = total;
     if (need > 0 && excl < need && need <= incl) {
-        uint32_t cum = excl;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (cum + h[i] >= need) { sh[4] = (uint32_t)(top - i); sh[5] = cum; break; }
-            cum += h[i];
-        }
+        if (excl + h0 >= need) { sh[16] = (uint32_t)top; sh[17] = excl; }
+        else { sh[16] = (uint32_t)(top - 1); sh[17] = excl + h0; }
     }
     __syncthreads();
-    bin = sh[4];
-    above = sh[5];
+    bin = sh[16];
+    above = sh[17];
+    __syncthreads();
 }
 
 // Zero-padded copy of the query block (rows beyond n_queries are zero) so that
@@ -399,7 +409,7 @@ hipError_t launch_batch_scan(const float* d_Q, uint32_t n_queries, const ScanArg
     }
 #undef TRAG_LAUNCH_GEMM
     const uint32_t n_tiles64 = (a.n_rows + 63) / 64;
-    hipLaunchKernelGGL(tau_select_kernel, dim3(n_queries), dim3(256), 0, st, s.tmax, s.tmax_stride,
+    hipLaunchKernelGGL(tau_select_kernel, dim3(n_queries), dim3(1024), 0, st, s.tmax, s.tmax_stride,
                        n_tiles64, s.ctls);
     return hipGetLastError();
 }
