@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows (whole job)")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 matrix cores")
+    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 f32 matrix cores, 4 bf16 prefilter + exact finish")
     ap.add_argument("--batch", type=int, default=1, help="queries per step (2..8: one multi-query exact pass; above: matrix-core path)")
     ap.add_argument("--sparse-vocab", type=int, default=50000)
     ap.add_argument("--sparse-tokens", type=int, default=64)
@@ -168,6 +168,7 @@ def main():
     elapsed = time.perf_counter() - t0
     scan_ms, scan_launches = store.scan_time()
     store.set_profiling(False)
+    mode_used = store.last_stats()["mode_used"]  # the path the timed steps actually took
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,7 +197,11 @@ def main():
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
         flops = 2.0 * B * n_local * d
         tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
-        mfma_bound = B >= 40  # 2*B*N*d flops over N*d*4 bytes vs 157.3 TF / 8 TB/s = 19.7 flop/B
+        # which roofline binds: 2*B*N*d flops over N*d*4 bytes against the peak of the matrix
+        # pipe the path uses (f32 157.3 TF: B >= 40; bf16 prefilter 2500 TF: B >= 625) and 8 TB/s
+        bf16 = mode_used == 4
+        mfma_peak = 2500.0 if bf16 else 157.3
+        mfma_bound = mode_used in (3, 4) and B / 2.0 >= mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         result = {
             "metric": "queries/sec, brute-force cosine top-10 over N x d fp32 (achieved HBM GB/s in roofline)",
             "value": args.steps * B / elapsed,
@@ -216,9 +221,13 @@ def main():
                        f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, cosine top-{k}",
                        "rows": n_total, "dim": d, "k": k, "batch": B, "metric": "cosine",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
-                       "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma"}[args.mode]},
-            "roofline": ({"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
-                          "frac": tflops / 157.3, "traffic": None, "flops_per_launch": flops}
+                       "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma", 4: "bf16-prefilter"}[args.mode],
+                       "path_used": {1: "exact scan (f32, reference order)", 2: "streaming scan + exact re-score",
+                                     3: "f32 matrix cores + exact re-score",
+                                     4: "bf16 matrix-core prefilter + exact f32 scoring of candidates"
+                                     }.get(mode_used, str(mode_used))},
+            "roofline": ({"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s",
+                          "frac": tflops / mfma_peak, "traffic": None, "flops_per_launch": flops}
                          if mfma_bound else
                          {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": achieved / HBM_PEAK_GBS, "traffic": None}),

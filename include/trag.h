@@ -53,9 +53,13 @@ typedef enum trag_scan_mode {
     TRAG_SCAN_AUTO = 0,
     TRAG_SCAN_EXACT = 1,  /* every row scored with the reference's sequential f32 order */
     TRAG_SCAN_STREAM = 2, /* reassociated streaming scan + exact re-score of candidates */
-    TRAG_SCAN_MFMA = 3    /* query batches as Q x D^T on the matrix cores + exact re-score
+    TRAG_SCAN_MFMA = 3,   /* query batches as Q x D^T on the matrix cores + exact re-score
                              (dim % 32 == 0); AUTO picks it above 8 queries;
                              2..8 queries share one exact corpus pass */
+    TRAG_SCAN_BF16 = 4    /* query batches: a bf16 matrix-core pass picks, per query, every row
+                             that can be in the top k (rigorous error bound), no score matrix is
+                             written, and those rows are scored exactly in f32 (dim % 64 == 0);
+                             AUTO prefers it to TRAG_SCAN_MFMA for large corpora */
 } trag_scan_mode;
 
 /* VectorStoreConfig, src/index.rs:283-307 (the hnsw_* fields are never read by

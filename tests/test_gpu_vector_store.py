@@ -623,3 +623,67 @@ def test_multi_query_device_entry(trag, oracle):
     for b in range(B):
         er, es = oracle.search(corpus, Q[b], k, 0)
         assert_same_ranking(o_rows[b].cpu().numpy().astype(np.uint32), o_scores[b].cpu().numpy(), er, es, f"dev {b}")
+
+
+# ---------------- bf16 matrix-core prefilter + exact f32 finish ----------------
+
+BF16 = 4
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,B", [(70_000, 384, 9), (100_000, 768, 40), (66_000, 64, 100), (80_000, 128, 200),
+                                   (131_072, 256, 300)])
+def test_bf16_prefilter_parity(trag, oracle, metric, n, d, B):
+    rng = np.random.default_rng(n + d + B)
+    corpus = unit_rows(rng, n, d) if metric == 0 else rng.standard_normal((n, d)).astype(np.float32)
+    corpus[17] = corpus[n - 5]            # duplicate rows in different tiles
+    corpus[1000] = 0.0                    # zero-norm row
+    corpus[2000] *= 1e-3                  # a short row
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[3] = corpus[17]                     # exact tie at the top
+    Q[4] = corpus[4242] * np.float32(1.0001) + np.float32(1e-4)   # a near-duplicate
+    Q[5] = 0.0                            # zero query: every cosine ties at 0.0 -> exact fallback
+    store = make_store(trag, d, metric, BF16)
+    store.insert_rows(corpus)
+    dead = np.zeros(n, dtype=np.uint8)
+    for r in (5, 64, 12_345, n - 5):
+        store.remove_row(r)
+        dead[r] = 1
+    for k in (10, 100):
+        rows, scores, cnt = store.search_batch_rows(Q, k)
+        assert cnt.tolist() == [k] * B
+        check = range(B) if B <= 40 else list(range(8)) + list(range(B - 8, B))
+        for b in check:
+            er, es = oracle.search(corpus, Q[b], k, metric, dead=dead)
+            assert_same_ranking(rows[b], scores[b], er, es, f"bf16 n={n} d={d} q={b} k={k} metric={metric}")
+        st = store.last_stats()
+        assert st["mode_used"] == BF16
+        assert st["fallbacks"] <= 3
+
+
+def test_bf16_auto_and_limits(trag, oracle):
+    n, d = 70_000, 384
+    store = make_store(trag, d, 0, 0, reserve=n)
+    store.fill_synthetic(n, 77)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(78, 0, 12, d)
+    rows, scores, cnt = store.search_batch_rows(Q, 10)
+    assert store.last_stats()["mode_used"] == BF16          # AUTO: above 8 queries, large corpus
+    for b in range(12):
+        er, es = oracle.search(corpus, Q[b], 10, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"auto bf16 {b}")
+    store.search_batch_rows(Q[:8], 10)
+    assert store.last_stats()["mode_used"] == EXACT         # 2..8 queries: one exact pass
+    store.search_batch_rows(Q, 300)
+    assert store.last_stats()["mode_used"] == MFMA          # k too large for the candidate lists
+    # clustered scores: thousands of rows within 2 eps of the k-th best overflow the lists -> exact repeat
+    near = (corpus[0][None, :] + 1e-3 * np.random.default_rng(1).standard_normal((6000, d))).astype(np.float32)
+    store2 = make_store(trag, d, 0, BF16)
+    c2 = np.concatenate([corpus[:66_000], near])
+    store2.insert_rows(c2)
+    Q2 = np.concatenate([corpus[0][None, :], Q[:9]]).astype(np.float32)
+    rows, scores, cnt = store2.search_batch_rows(Q2, 10)
+    for b in range(10):
+        er, es = oracle.search(c2, Q2[b], 10, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"clustered bf16 {b}")
+    assert store2.last_stats()["fallbacks"] >= 1

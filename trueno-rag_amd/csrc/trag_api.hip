@@ -71,6 +71,9 @@ struct trag_store {
     float* d_vmax_sq = nullptr;    // 1 float
     float* d_norm2 = nullptr;      // cap_rows squared row norms (batched cosine epilogue)
     BatchScratch batch{};
+    Bf16Scratch bf16{};
+    uint64_t bf16_tiles_cap = 0;   // tile maxima per query the bf16 scratch holds
+    uint32_t bf16_q_cap = 0;
     uint64_t batch_rows_cap = 0;   // rows the batch scratch was sized for
     uint32_t batch_q_cap = 0;
     // search scratch (one query in flight per handle)
@@ -256,6 +259,37 @@ trag_status ensure_batch_scratch(trag_store* s, uint32_t nq) {
     return TRAG_OK;
 }
 
+trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
+    const uint32_t qcap = std::min<uint32_t>(std::max<uint32_t>(nq, 1), BATCH_QUERIES);
+    const uint64_t tiles = (uint64_t)s->cap_rows / 32 + 32;  // one maximum per 32 rows, sample step 1 at worst
+    if (s->bf16.qb && s->bf16_tiles_cap >= tiles && s->bf16_q_cap >= qcap) return TRAG_OK;
+    void* old[] = {s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand};
+    for (void* p : old)
+        if (p) (void)hipFree(p);
+    s->bf16 = Bf16Scratch{};
+    s->bf16_tiles_cap = 0;
+    s->bf16_q_cap = 0;
+    const size_t padded = ((size_t)qcap + 255) / 256 * 256;
+    // the sample pass covers at most every tile (step 1) but normally 1/8 of them
+    s->bf16.tmax_stride = (size_t)tiles;
+    HIP_TRY(hipMalloc(&s->bf16.qb, padded * s->cfg.dim * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc(&s->bf16.thr, (size_t)qcap * sizeof(float)));
+    HIP_TRY(hipMalloc(&s->bf16.ctls, (size_t)qcap * sizeof(SearchCtl)));
+    HIP_TRY(hipMalloc(&s->bf16.tmax, (size_t)qcap * s->bf16.tmax_stride * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->bf16.cand, (size_t)qcap * CAND_CAP * sizeof(uint32_t)));
+    s->bf16_tiles_cap = tiles;
+    s->bf16_q_cap = qcap;
+    return TRAG_OK;
+}
+
+// The bf16 prefilter serves batches above 8 queries on corpora large enough for its
+// sample pass to be meaningful; k must leave room in the candidate lists.
+bool use_bf16_path(const trag_store* s, uint32_t mode, uint32_t nq, uint32_t k) {
+    if (!bf16_supports(s->cfg.dim, s->cfg.metric) || s->n_rows < 65536 || k > 256) return false;
+    if (mode == TRAG_SCAN_BF16) return true;
+    return mode == TRAG_SCAN_AUTO && nq > 8;
+}
+
 // Batches go to the matrix cores when the mode asks for it, or by default above
 // 8 queries, if the metric/dimension have a kernel and the corpus is not tiny.
 // Up to 8 queries one multi-query exact pass (HBM-bound) is as fast as the
@@ -271,9 +305,17 @@ uint32_t pick_mode(const trag_store* s, uint32_t requested) {
     uint32_t mode = requested;
     // The exact-order scan measured faster than the streaming one on MI355X (it
     // needs no re-score), so it is the default for every dimension.
-    if (mode == TRAG_SCAN_AUTO || mode == TRAG_SCAN_MFMA) mode = TRAG_SCAN_EXACT;
+    if (mode == TRAG_SCAN_AUTO || mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16) mode = TRAG_SCAN_EXACT;
     if (mode == TRAG_SCAN_STREAM && !stream_supports_dim(s->cfg.dim)) mode = TRAG_SCAN_EXACT;
     return mode;
+}
+
+uint32_t choose_mode(const trag_store* s, uint32_t n_queries, uint32_t k) {
+    const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, s->n_live);
+    if (use_bf16_path(s, s->cfg.scan_mode, n_queries, k_eff)) return TRAG_SCAN_BF16;
+    const uint32_t asked = s->cfg.scan_mode == TRAG_SCAN_BF16 ? (uint32_t)TRAG_SCAN_AUTO : s->cfg.scan_mode;
+    if (use_batch_path(s, asked, n_queries)) return TRAG_SCAN_MFMA;
+    return pick_mode(s, s->cfg.scan_mode);
 }
 
 // Enqueue the pipeline for n_queries device-resident queries on `st`.
@@ -309,6 +351,35 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             HIP_TRY(hipMemsetAsync(s->scratch.hist, 0, s->zero_bytes - 256, st));
         }
         s->stats.mode_used = TRAG_SCAN_EXACT;
+        return TRAG_OK;
+    }
+    if (mode == TRAG_SCAN_BF16) {
+        ts = ensure_bf16_scratch(s, n_queries);
+        if (ts != TRAG_OK) return ts;
+        ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+        for (uint32_t b0 = 0; b0 < n_queries; b0 += BATCH_QUERIES) {
+            const uint32_t nb = std::min<uint32_t>(BATCH_QUERIES, n_queries - b0);
+            const float* Qb = d_queries + (size_t)b0 * s->cfg.dim;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (s->profiling && s->ev_used < 4096) {
+                if (s->ev_used == s->ev_pool.size()) {
+                    hipEvent_t a0, a1;
+                    HIP_TRY(hipEventCreate(&a0));
+                    HIP_TRY(hipEventCreate(&a1));
+                    s->ev_pool.emplace_back(a0, a1);
+                }
+                e0 = s->ev_pool[s->ev_used].first;
+                e1 = s->ev_pool[s->ev_used].second;
+                s->ev_used += 1;
+                HIP_TRY(hipEventRecord(e0, st));
+            }
+            HIP_TRY(launch_bf16_scan(Qb, nb, a, s->d_norm2, s->bf16, k_eff, k_eff, s->d_vmax_sq, st));
+            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(launch_bf16_finish(Qb, nb, a, s->bf16, live, k, d_out_rows + (size_t)b0 * k,
+                                       d_out_scores + (size_t)b0 * k, d_out_n + b0,
+                                       d_status ? d_status + b0 : nullptr, st));
+        }
+        s->stats.mode_used = mode;
         return TRAG_OK;
     }
     if (mode == TRAG_SCAN_MFMA) {
@@ -420,7 +491,7 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
     *out = nullptr;
     if (cfg->dim == 0) return fail(TRAG_INVALID_CONFIG, "dimension must be positive");
     if (cfg->metric > TRAG_DOT_PRODUCT) return fail(TRAG_INVALID_CONFIG, "unknown metric");
-    if (cfg->scan_mode > TRAG_SCAN_MFMA) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    if (cfg->scan_mode > TRAG_SCAN_BF16) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -454,7 +525,7 @@ void trag_store_destroy(trag_store* s) {
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->batch.qpad, s->batch.ctls,
-                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax, s->d_sort, s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
+                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax, s->d_sort, s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
                     s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -582,8 +653,7 @@ trag_status trag_store_search_device(trag_store* s, const float* d_queries, uint
         if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, n_queries * sizeof(uint32_t), st));
         return TRAG_OK;
     }
-    const uint32_t mode = use_batch_path(s, s->cfg.scan_mode, n_queries) ? (uint32_t)TRAG_SCAN_MFMA
-                                                                          : pick_mode(s, s->cfg.scan_mode);
+    const uint32_t mode = choose_mode(s, n_queries, k);
     return enqueue_search(s, d_queries, n_queries, k, mode, d_out_rows, d_out_scores, d_out_n,
                           d_status, st);
 }
@@ -609,8 +679,7 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
     hipStream_t st = s->stream;
     HIP_TRY(hipMemcpyAsync(s->d_q, queries, (size_t)n_queries * dim * sizeof(float),
                            hipMemcpyHostToDevice, st));
-    uint32_t mode = use_batch_path(s, s->cfg.scan_mode, n_queries) ? (uint32_t)TRAG_SCAN_MFMA
-                                                                   : pick_mode(s, s->cfg.scan_mode);
+    uint32_t mode = choose_mode(s, n_queries, k);
     ts = enqueue_search(s, s->d_q, n_queries, k, mode, s->d_out_rows, s->d_out_scores, s->d_out_n,
                         s->d_out_status, st);
     if (ts != TRAG_OK) return ts;
@@ -634,7 +703,7 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
         for (int attempt = 0; attempt < 3 && status[b] != ST_OK; ++attempt) {
             if (status[b] == ST_NEED_REFINE) {
                 s->full_select = true;
-                if (cur_mode == TRAG_SCAN_MFMA) cur_mode = TRAG_SCAN_EXACT;
+                if (cur_mode == TRAG_SCAN_MFMA || cur_mode == TRAG_SCAN_BF16) cur_mode = TRAG_SCAN_EXACT;
             } else {
                 s->stats.fallbacks += 1;
                 cur_mode = TRAG_SCAN_EXACT;
@@ -656,9 +725,10 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
                                                std::to_string(status[b]) + ")");
     }
     s->stats.mode_used = mode;
-    if (mode == TRAG_SCAN_MFMA) {
+    if (mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16) {
         SearchCtl ctl;
-        HIP_TRY(hipMemcpy(&ctl, s->batch.ctls, sizeof(ctl), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&ctl, mode == TRAG_SCAN_BF16 ? s->bf16.ctls : s->batch.ctls, sizeof(ctl),
+                          hipMemcpyDeviceToHost));
         s->stats.candidates = ctl.cand_count;
         s->stats.refine_levels = 0;
     } else {
@@ -677,7 +747,7 @@ trag_status trag_store_search(trag_store* s, const float* query, uint32_t dim, u
 
 trag_status trag_store_set_scan_mode(trag_store* s, uint32_t scan_mode) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
-    if (scan_mode > TRAG_SCAN_MFMA) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    if (scan_mode > TRAG_SCAN_BF16) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
     std::lock_guard<std::mutex> lk(s->mu);
     s->cfg.scan_mode = scan_mode;
     return TRAG_OK;

@@ -370,6 +370,19 @@ pad_queries_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t pad
     }
 }
 
+hipError_t launch_batch_prep(const float* d_Q, uint32_t n_queries, uint32_t dim, SearchCtl* ctls,
+                             uint32_t need, uint32_t k, const float* d_vmax_sq, hipStream_t st) {
+    hipLaunchKernelGGL(prep_batch_kernel, dim3(n_queries), dim3(256), 0, st, d_Q, dim, ctls, need, k,
+                       d_vmax_sq);
+    return hipGetLastError();
+}
+
+void launch_tau_select(const uint32_t* tmax, size_t tmax_stride, uint32_t n_tiles64, SearchCtl* ctls,
+                       uint32_t n_queries, hipStream_t st) {
+    hipLaunchKernelGGL(tau_select_kernel, dim3(n_queries), dim3(1024), 0, st, tmax, tmax_stride, n_tiles64,
+                       ctls);
+}
+
 bool batch_supports(uint32_t dim, uint32_t metric) {
     return (dim % BT_KMIN) == 0 && metric <= TRAG_DOT_PRODUCT;
 }

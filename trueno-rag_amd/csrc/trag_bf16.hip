@@ -1,0 +1,359 @@
+// Query batches with a bf16 matrix-core PREFILTER and an exact f32 finish.
+//
+// The returned rows and scores are the reference's f32 results, bit for bit:
+// the bf16 pass only decides which rows can possibly be in a query's top k.
+//
+//   1. a sample of the corpus tiles (every tile_step-th) goes through the GEMM;
+//      per query the k-th largest tile maximum A_k of the sample is a score that
+//      at least k live rows reach approximately;
+//   2. every approximate score is within eps of the reference's f32 score
+//      (bf16 rounding of both operands, 2^-9 relative each, plus f32
+//      accumulation; bound below), so the exact k-th best is >= A_k - eps and
+//      every row of the exact top k has an approximate score >= A_k - 2 eps;
+//   3. the full GEMM pass appends exactly those rows to the query's candidate
+//      list (no score matrix is written: the pass reads the corpus once and
+//      writes a few hundred row ids per query);
+//   4. the candidates are re-scored with the reference arithmetic, sorted, and
+//      the bound is checked once more against the exact k-th score (final_kernel).
+// A candidate list that overflows, or a query outside the bound's range
+// (non-finite norms), is repeated with the exact scan by the host.
+//
+// With 2.5 PFLOP/s of dense bf16 the pass is bound by the HBM read of the f32
+// corpus (converted to bf16 on the way into LDS) up to several hundred queries.
+#include <algorithm>
+
+#include "trag_device.h"
+#include "trag_internal.h"
+
+namespace trag {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BF_K = 64;   // f32 columns staged per step (= 4 MFMA k-steps of 16)
+constexpr int BF_LD = 36;  // dwords per LDS row: 64 bf16 + 4 dwords of padding (conflict-free b128 reads)
+
+// Queries -> bf16, zero-padded to `padded` rows.
+__global__ void __launch_bounds__(256)
+queries_to_bf16_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t padded, uint32_t d,
+                       __bf16* __restrict__ out) {
+    const size_t total4 = (size_t)padded * d / 4;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
+        const size_t q = (e * 4) / d;
+        v4f x = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (q < n_queries) x = reinterpret_cast<const v4f*>(Q)[e];
+        reinterpret_cast<bf16x4*>(out)[e] = __builtin_convertvector(x, bf16x4);
+    }
+}
+
+// After tau_select on the sample's tile maxima, which are keys of the row-dependent part
+// v of the score (cosine v = dot * inv_nb = score * ||q||; dot product v = score;
+// Euclidean v = 2 dot - ||v||^2 = -(squared distance) + ||q||^2): lower each query's
+// threshold by 2 eps (see the header), publish it in v-space for the full pass, and
+// keep it in score space (t_key) for the final check. A query whose scale is outside
+// the bound's range gets the threshold -inf: its list overflows and the host repeats it
+// with the exact scan.
+template <int METRIC>
+__global__ void shift_threshold_kernel(SearchCtl* __restrict__ ctls, uint32_t n_queries, uint32_t d,
+                                       float* __restrict__ thr) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    SearchCtl* ctl = ctls + q;
+    const uint32_t tk = ctl->t_key;
+    const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
+    float t = -INFINITY, v = -INFINITY;
+    const bool in_range = na * vmax < 1e30f && (METRIC != 0 || na > 0.0f);  // false for NaN too
+    if (tk >= 0x007FFFFFu && in_range) {
+        const float eps = bf16_eps<METRIC>(d, na, vmax);
+        const float tv = key_score(tk);
+        if (METRIC == 0) { t = tv / na - 2.02f * eps; v = t * na; }
+        else if (METRIC == 1) { t = (tv - ctl->na_sq) - 2.02f * eps; v = t + ctl->na_sq; }
+        else { t = tv - 2.02f * eps; v = t; }
+    }
+    if (!(t == t) || !(v == v)) { t = -INFINITY; v = -INFINITY; }
+    ctl->t_key = t > -INFINITY ? score_key(t) : 1u;
+    thr[q] = v;
+}
+
+// ---------------------------------------------------------------------------
+// The GEMM. WGM (queries) x WGN (rows) waves; each wave owns TM x 2
+// tiles of v_mfma_f32_32x32x16_bf16, i.e. 32*TM queries x 64 corpus rows.
+// MFMA roles as in the f32 kernel: A = queries (accumulator rows), B = corpus
+// rows (accumulator columns = lanes). Lane l (r = l & 31, h = l >> 5) feeds
+// A[row r][k = 8h..8h+7] and B[k = 8h..8h+7][col r]: one 16-byte LDS read each
+// from row-major bf16 images with a 144-byte row stride.
+// MODE 0: sample pass, writes per-(query, 64-row tile) maxima as ordered keys.
+// MODE 1: full pass, appends rows whose approximate score reaches thr[query].
+// METRIC: 0 cosine, 1 Euclidean, 2 dot product.
+// ---------------------------------------------------------------------------
+template <int METRIC, int TM, int WGM, int WGN, int MODE>
+__global__ void __launch_bounds__(64 * WGM * WGN)
+gemm_bf16_kernel(const float* __restrict__ corpus, const __bf16* __restrict__ Qb,
+                 const float* __restrict__ norm2, const uint32_t* __restrict__ dead, uint32_t n_rows,
+                 uint32_t d, uint32_t n_queries, uint32_t q_tiles, uint32_t tile_step,
+                 SearchCtl* __restrict__ ctls, const float* __restrict__ thr,
+                 uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_t* __restrict__ cand) {
+    constexpr int NT = 64 * WGM * WGN;  // threads
+    constexpr int PF = 1;               // steps of operand loads in flight (2 and 3 measured slower)
+    constexpr int BM = 32 * TM * WGM;   // queries per workgroup tile
+    constexpr int BN = 64 * WGN;        // corpus rows per workgroup tile
+    constexpr int NLA = BM * 8 / NT;    // 16-byte chunks of the query tile per thread and step
+    constexpr int NLB = BN * 16 / NT;   // 16-byte chunks (4 f32) of the corpus tile per thread and step
+    __shared__ __attribute__((aligned(16))) uint32_t As[BM * BF_LD];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[BN * BF_LD];
+    __shared__ __attribute__((aligned(16))) float qs_s[BM];  // MODE 1: the queries' thresholds
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid % WGN;
+
+    // workgroups sharing a corpus tile (different query tiles) are adjacent on one XCD
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, i8 = b >> 3;
+    const uint32_t qt = i8 % q_tiles;
+    const uint32_t nts = (i8 / q_tiles) * 8u + xcd;  // index among the tiles of this pass
+    const uint32_t nt = nts * tile_step;
+    const uint32_t n_row_tiles = (n_rows + BN - 1) / BN;
+    if (nt >= n_row_tiles) return;
+    const uint32_t q0 = qt * BM, n0 = nt * BN;
+
+    if (MODE == 1 && tid < BM) qs_s[tid] = (q0 + tid < n_queries) ? thr[q0 + tid] : INFINITY;
+
+    const uint32_t nk = d / BF_K;
+    const u32x4* aptr[NLA];
+    const float* bptr[NLB];
+    int a_off[NLA], b_off[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int c = tid + NT * i, row = c >> 3, col = c & 7;
+        aptr[i] = reinterpret_cast<const u32x4*>(Qb + (size_t)(q0 + row) * d) + col;
+        a_off[i] = row * BF_LD + col * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int c = tid + NT * i, row = c >> 4, col = c & 15;
+        const uint32_t r = min(n0 + (uint32_t)row, n_rows - 1u);
+        bptr[i] = corpus + (size_t)r * d + col * 4;
+        b_off[i] = row * BF_LD + col * 2;
+    }
+    // PF steps of operand loads are kept in flight in registers: with one or two waves per
+    // SIMD a single step in flight leaves the pass bound by HBM latency, not bandwidth
+    u32x4 ra[PF][NLA];
+    v4f rb[PF][NLB];
+    auto prefetch = [&](int slot, uint32_t kt) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) ra[slot][i] = aptr[i][kt * (BF_K / 8)];
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            rb[slot][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i] + (size_t)kt * BF_K));
+    };
+    auto stage = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) *reinterpret_cast<u32x4*>(&As[a_off[i]]) = ra[slot][i];
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const bf16x4 h = __builtin_convertvector(rb[slot][i], bf16x4);
+            *reinterpret_cast<u32x2*>(&Bs[b_off[i]]) = __builtin_bit_cast(u32x2, h);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s)
+        if ((uint32_t)s < nk) prefetch(s, (uint32_t)s);
+
+    v16f acc[TM][2];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    const int frow = lane & 31, half = lane >> 5;
+    for (uint32_t kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const uint32_t kt = kt0 + (uint32_t)s;
+            if (kt < nk) {  // uniform over the workgroup
+                __syncthreads();
+                stage(s);
+                __syncthreads();
+                if (kt + PF < nk) prefetch(s, kt + PF);
+#pragma unroll
+                for (int ks = 0; ks < BF_K / 16; ++ks) {
+                    bf16x8 fa[TM], fb[2];
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+                        fa[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                            &As[(wm * 32 * TM + m * 32 + frow) * BF_LD + ks * 8 + half * 4]));
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        fb[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                            &Bs[(wn * 64 + n * 32 + frow) * BF_LD + ks * 8 + half * 4]));
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue. v = the row-dependent part of the score, per accumulator:
+    //   cosine dot * inv_nb, dot product dot, Euclidean 2 dot - ||v||^2
+    // as one fma(dot, scale, -shift) with per-lane (= per corpus row) constants. Rows that
+    // take no part (removed, beyond the corpus) get scale 0 and shift +inf (v = -inf); rows
+    // whose norm is outside the bound's range must always be candidates: MODE 1 gives
+    // them scale 0 and shift -inf (v = +inf), MODE 0 leaves them out of the sample.
+    uint32_t rows_[2];
+    float scale[2], nshift[2];
+    bool live[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const uint32_t row = n0 + wn * 64 + n * 32 + (uint32_t)frow;
+        rows_[n] = row;
+        live[n] = row < n_rows && !row_is_dead(dead, row);
+        float nb2 = 1.0f;
+        bool forced = false;
+        if (METRIC != 2) {
+            nb2 = row < n_rows ? norm2[row] : 0.0f;
+            forced = !(nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY));
+        }
+        float sc = METRIC == 0 ? (nb2 > 0.0f ? 1.0f / sqrtf(nb2) : 0.0f) : (METRIC == 1 ? 2.0f : 1.0f);
+        float sh = METRIC == 1 ? -nb2 : 0.0f;
+        if (forced) { sc = 0.0f; sh = MODE == 1 ? INFINITY : -INFINITY; }
+        if (!live[n]) { sc = 0.0f; sh = -INFINITY; }
+        scale[n] = sc;
+        nshift[n] = sh;
+    }
+    if (MODE == 0) {
+        // per (query, 32 rows): the largest v, as an ordered key. The 32 rows are those of 16
+        // lanes x 2 accumulator tiles; the 16-lane maximum costs four DPP steps.
+        const uint32_t tile32 = (nts * (uint32_t)(BN / 64) + (uint32_t)wn) * 2u + (uint32_t)((lane >> 4) & 1);
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qi = wm * 32 * TM + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const uint32_t q = q0 + (uint32_t)qi;
+                const float v0 = __builtin_fmaf(acc[m][0][r], scale[0], nshift[0]);
+                const float v1 = __builtin_fmaf(acc[m][1][r], scale[1], nshift[1]);
+                float best = fmaxf(v0, v1);  // fmaxf drops a NaN operand
+                best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(
+                                       __float_as_int(best), __float_as_int(best), 0xB1, 0xF, 0xF, false)));
+                best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(
+                                       __float_as_int(best), __float_as_int(best), 0x4E, 0xF, 0xF, false)));
+                best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(
+                                       __float_as_int(best), __float_as_int(best), 0x141, 0xF, 0xF, false)));
+                best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(
+                                       __float_as_int(best), __float_as_int(best), 0x140, 0xF, 0xF, false)));
+                if ((lane & 15) == 0 && q < n_queries)
+                    tmax[q * tmax_stride + tile32] = (best > -INFINITY && best < INFINITY) ? score_key(best) : 0u;
+            }
+        }
+    } else {
+        // hits are rare (a few hundred rows per query and million rows): first one fma and one
+        // compare per accumulator into a per-lane bit mask, then a loop over the set bits
+        uint32_t wmask[TM];
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            uint32_t w = 0u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4f th = *reinterpret_cast<const v4f*>(&qs_s[wm * 32 * TM + m * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = g * 4 + e;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const float v = __builtin_fmaf(acc[m][n][r], scale[n], nshift[n]);
+                        w |= !(v < th[e]) ? (1u << (n * 16 + r)) : 0u;  // NaN counts as a hit
+                    }
+                }
+            }
+            wmask[m] = w;
+        }
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            uint32_t w = wmask[m];
+            while (w) {
+                const uint32_t bit = (uint32_t)__ffs((int)w) - 1u;
+                w &= w - 1u;
+                const uint32_t n = bit >> 4, r = bit & 15u;
+                const uint32_t q = q0 + (uint32_t)(wm * 32 * TM + m * 32) + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)half;
+                const bool ok = n ? live[1] : live[0];
+                if (ok && q < n_queries) {
+                    const uint32_t pos = atomicAdd(&ctls[q].cand_count, 1u);
+                    if (pos < CAND_CAP) cand[(size_t)q * CAND_CAP + pos] = n ? rows_[1] : rows_[0];
+                }
+            }
+        }
+    }
+}
+
+bool bf16_supports(uint32_t dim, uint32_t metric) {
+    return (dim % BF_K) == 0 && metric <= TRAG_DOT_PRODUCT;
+}
+
+// Corpus tiles per sampled tile: the sample must hold many more 64-row tiles
+// than the rows wanted, or its k-th tile maximum says little.
+uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need) {
+    const uint64_t n_tile64 = (n_rows + 63) / 64;
+    const uint64_t step = n_tile64 / (64ull * (need ? need : 1));
+    return (uint32_t)(step < 1 ? 1 : (step > 8 ? 8 : step));
+}
+
+template <int METRIC, int MODE>
+static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const float* d_norm2, const Bf16Scratch& s,
+                             uint32_t tile_step, hipStream_t st) {
+    const int variant = n_queries <= 32 ? 0 : (n_queries <= 64 ? 1 : (n_queries <= 128 ? 2 : 3));
+    const uint32_t BM = variant == 0 ? 32 : (variant == 1 ? 64 : (variant == 2 ? 128 : 256));
+    const uint32_t BN = variant <= 1 ? 256 : 128;
+    const uint32_t q_tiles = (n_queries + BM - 1) / BM;
+    const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
+    const uint32_t pass_tiles = (n_row_tiles + tile_step - 1) / tile_step;
+    const uint32_t grid = ((pass_tiles + 7) / 8) * q_tiles * 8;
+#define TRAG_LAUNCH_BF16(TM, WGM, WGN)                                                                       \
+    hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, TM, WGM, WGN, MODE>), dim3(grid), dim3(64 * WGM * WGN), 0, st, \
+                       a.corpus, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, a.dim,       \
+                       n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand)
+    if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
+    else if (variant == 1) TRAG_LAUNCH_BF16(2, 1, 4);  // 64 x 256
+    else if (variant == 2) TRAG_LAUNCH_BF16(2, 2, 2);  // 128 x 128
+    else TRAG_LAUNCH_BF16(2, 4, 2);                    // 256 x 128, eight waves (two per SIMD)
+#undef TRAG_LAUNCH_BF16
+}
+
+// prep (norms, control blocks) is done by the caller with launch_batch_prep.
+template <int METRIC>
+static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const float* d_norm2,
+                             const Bf16Scratch& s, uint32_t need, hipStream_t st) {
+    const uint32_t padded = (n_queries + 255u) / 256u * 256u;
+    hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min<uint32_t>(1024, (padded * a.dim / 4 + 255) / 256)),
+                       dim3(256), 0, st, d_Q, n_queries, padded, a.dim, reinterpret_cast<__bf16*>(s.qb));
+    const uint32_t step = bf16_sample_step(a.n_rows, need);
+    launch_gemm_bf16<METRIC, 0>(n_queries, a, d_norm2, s, step, st);
+    // 64-row tiles the sample pass wrote maxima for (its last 128/256-row tile may be partial)
+    const uint32_t BN = n_queries <= 64 ? 256 : 128;
+    const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
+    const uint32_t pass_tiles = (n_row_tiles + step - 1) / step;
+    const uint32_t n_tile64 = pass_tiles * (BN / 32);  // maxima per 32 rows; every sampled workgroup writes all of its own
+    launch_tau_select(s.tmax, s.tmax_stride, n_tile64, s.ctls, n_queries, st);
+    hipLaunchKernelGGL(shift_threshold_kernel<METRIC>, dim3((n_queries + 255) / 256), dim3(256), 0, st, s.ctls,
+                       n_queries, a.dim, s.thr);
+    launch_gemm_bf16<METRIC, 1>(n_queries, a, d_norm2, s, 1, st);
+}
+
+hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const float* d_norm2,
+                            const Bf16Scratch& s, uint32_t need, uint32_t k, const float* d_vmax_sq,
+                            hipStream_t st) {
+    hipError_t e = launch_batch_prep(d_Q, n_queries, a.dim, s.ctls, need, k, d_vmax_sq, st);
+    if (e != hipSuccess) return e;
+    if (a.metric == TRAG_COSINE) bf16_scan_metric<0>(d_Q, n_queries, a, d_norm2, s, need, st);
+    else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1>(d_Q, n_queries, a, d_norm2, s, need, st);
+    else bf16_scan_metric<2>(d_Q, n_queries, a, d_norm2, s, need, st);
+    return hipGetLastError();
+}
+
+}  // namespace trag

@@ -44,6 +44,26 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+// bf16 prefilter: largest |approximate - reference| of a score, as a multiple of
+// the scale ||q|| * ||v|| (cosine: of 1): both operands rounded to bf16
+// (2 * 2^-9 + 2^-18), d f32 accumulation steps of unknown rounding (2^-22 each),
+// and the rounding of the reference's own sequential sum and norms ((2d + 64) * 2^-24).
+__device__ __forceinline__ float bf16_unit_eps(uint32_t d) {
+    const float fd = (float)d;
+    return (0.00390625f * 1.002f + fd * 2.3841858e-07f * 1.01f + (2.0f * fd + 64.0f) * 5.9604645e-08f) * 1.01f;
+}
+
+// The same bound in the key space of each metric (0 cosine: score; 2 dot
+// product: score; 1 Euclidean: negated squared distance).
+template <int METRIC>
+__device__ __forceinline__ float bf16_eps(uint32_t d, float na, float vmax) {
+    const float c = bf16_unit_eps(d);
+    if (METRIC == 0) return c + 1e-30f;
+    if (METRIC == 2) return c * na * vmax + 1e-30f;
+    const float span = na + vmax;
+    return 2.0f * c * na * vmax + (2.0f * (float)d + 64.0f) * 5.9604645e-08f * span * span * 1.01f + 1e-30f;
+}
+
 // Same integer hash as the host generator used by the tests.
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;

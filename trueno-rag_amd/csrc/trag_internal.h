@@ -68,6 +68,16 @@ struct BatchScratch {
     uint32_t* cand;      // [queries][CAND_CAP]
 };
 
+// Device scratch of a block of queries on the bf16-prefilter path (no score matrix).
+struct Bf16Scratch {
+    uint16_t* qb;        // queries as bf16, zero-padded to a multiple of 256 rows
+    float* thr;          // per query: the full pass's candidate threshold
+    SearchCtl* ctls;     // one per query
+    uint32_t* tmax;      // [queries][tmax_stride]: tile maxima of the sample pass
+    size_t tmax_stride;
+    uint32_t* cand;      // [queries][CAND_CAP]
+};
+
 constexpr uint32_t ST_OVERFLOW = 2;     // more candidates than the final sort holds: repeat exactly
 constexpr uint32_t BATCH_QUERIES = 256; // queries processed per batched pass
 
@@ -138,6 +148,20 @@ hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanA
                                const BatchScratch& s, uint32_t live, uint32_t out_stride,
                                uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
                                uint32_t* d_status, hipStream_t st);
+// pieces of the batched path reused by the bf16 prefilter
+hipError_t launch_batch_prep(const float* d_Q, uint32_t n_queries, uint32_t dim, SearchCtl* ctls,
+                             uint32_t need, uint32_t k, const float* d_vmax_sq, hipStream_t st);
+void launch_tau_select(const uint32_t* tmax, size_t tmax_stride, uint32_t n_tiles64, SearchCtl* ctls,
+                       uint32_t n_queries, hipStream_t st);
+// bf16 prefilter (trag_bf16.hip) and its exact finish (trag_kernels.hip)
+bool bf16_supports(uint32_t dim, uint32_t metric);
+uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need);
+hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const float* d_norm2,
+                            const Bf16Scratch& s, uint32_t need, uint32_t k, const float* d_vmax_sq,
+                            hipStream_t st);
+hipError_t launch_bf16_finish(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const Bf16Scratch& s,
+                              uint32_t live, uint32_t out_stride, uint32_t* d_out_rows, float* d_out_scores,
+                              uint32_t* d_out_n, uint32_t* d_status, hipStream_t st);
 hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint32_t dim,
                                  uint64_t seed, float* d_norm_tmp, hipStream_t st);
 hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_list_n,

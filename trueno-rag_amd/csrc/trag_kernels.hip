@@ -600,9 +600,12 @@ __device__ float exact_score_row(const float* __restrict__ v, const float* __res
 // Streaming / batched modes: every row left behind has an approximate score
 // <= t (the select threshold) and approximate and exact scores differ by at
 // most eps, so the exact top-k is final when its last member clears t + eps.
+// key_mode: 0 keys are approximate scores of the streaming / f32 matrix-core pass;
+// 2 keys of the f32 matrix-core Euclidean pass (negated squared distance);
+// 3 keys of the bf16 prefilter (Euclidean: negated squared distance).
 template <int METRIC>
 __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float na, uint32_t t_key,
-                            float ek, bool sq_keys = false) {
+                            float ek, int key_mode = 0) {
     uint32_t status = ST_OK;
     const float u = 5.9604645e-08f;  // 2^-24
     float eps = (2.0f * (float)d + 64.0f) * u;
@@ -610,22 +613,22 @@ __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float
     // the bound assumes ||q||^2 is a normal number well inside the f32 range
     const float nsq = ctl->na_sq;
     if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f))) status = ST_UNCERTIFIED;
-    if (METRIC == 1 && sq_keys) {
-        // Matrix-core Euclidean pass: keys order -(||q||^2 + ||v||^2 - 2 q.v), an approximation of
-        // the negated SQUARED distance with absolute error <= eps * (||q|| + ||v||)^2. Every row
-        // left behind has approximate squared distance >= T2 = -t; the exact k-th distance
-        // (squared, plus the rounding of the exact path) must stay below T2 minus that error.
+    const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
+    if (METRIC == 1 && key_mode >= 2) {
+        // Keys order -(||q||^2 + ||v||^2 - 2 q.v), an approximation of the negated SQUARED
+        // distance with absolute error <= eps2. Every row left behind has approximate squared
+        // distance >= T2 = -t; the exact k-th distance (squared, plus the rounding of the
+        // exact path) must stay below T2 minus that error.
         const float span = na + vmax;
-        const float eps2 = eps * span * span * 1.01f + 1e-30f;
-        const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
+        const float eps2 = key_mode == 3 ? bf16_eps<1>(d, na, vmax) : eps * span * span * 1.01f + 1e-30f;
         const float T2 = -t;
         const float dk2 = ek * ek * (1.0f + eps);
         if (!(dk2 + eps2 < T2) || !(eps2 < INFINITY)) status = ST_UNCERTIFIED;
         return status;
     }
-    if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
-    if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
-    const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
+    if (key_mode == 3) eps = bf16_eps<METRIC>(d, na, vmax);
+    else if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
+    else if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
     if (!(ek > t + eps) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
     return status;
 }
@@ -652,8 +655,8 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
         if (out_status) out_status += y;
     }
     // use_count != 0: the candidates were gathered against a given threshold and
-    // their number is only known from the append cursor; 2: the keys are in the
-    // squared-distance space of the matrix-core Euclidean pass (see certify)
+    // their number is only known from the append cursor; 2 and 3 also name the
+    // key space of the pass that gathered them (certify's key_mode)
     uint32_t C = use_count ? ctl->cand_count : ctl->expect;
     const bool overflow = C > CAND_CAP;
     if (C > CAND_CAP) C = CAND_CAP;
@@ -700,7 +703,7 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
         uint32_t status = ST_OK;
         if (RESCORE && C < live && n_out > 0)
             status = certify<METRIC>(ctl, d, na, ctl->t_key, key_score((uint32_t)(sk[n_out - 1] >> 32)),
-                                     use_count == 2);
+                                     use_count >= 2 ? use_count : 0);
         if (overflow) status = ST_OVERFLOW;
         ctl->levels = ctl->resolved ? ctl->resolved : 3;
         ctl->status = status;
@@ -1403,6 +1406,20 @@ hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanA
         hipLaunchKernelGGL((final_kernel<2, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,
                            a.n_rows, a.dim, live, s.ctls, s.keys, s.cand, d_out_rows, d_out_scores,
                            d_out_n, d_status, s.keys_stride, out_stride, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_bf16_finish(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const Bf16Scratch& s,
+                              uint32_t live, uint32_t out_stride, uint32_t* d_out_rows, float* d_out_scores,
+                              uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
+#define TRAG_BF16_FINAL(METRIC)                                                                           \
+    hipLaunchKernelGGL((final_kernel<METRIC, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,   \
+                       a.n_rows, a.dim, live, s.ctls, (const uint32_t*)nullptr, s.cand, d_out_rows,       \
+                       d_out_scores, d_out_n, d_status, (size_t)0, out_stride, 3)
+    if (a.metric == TRAG_COSINE) TRAG_BF16_FINAL(0);
+    else if (a.metric == TRAG_EUCLIDEAN) TRAG_BF16_FINAL(1);
+    else TRAG_BF16_FINAL(2);
+#undef TRAG_BF16_FINAL
     return hipGetLastError();
 }
 
