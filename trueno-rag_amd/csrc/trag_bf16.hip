@@ -304,12 +304,21 @@ uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need) {
     return (uint32_t)(step < 1 ? 1 : (step > 8 ? 8 : step));
 }
 
+// workgroup tile by batch size: queries x corpus rows
+static int bf16_variant(uint32_t n_queries) {
+    return n_queries <= 32 ? 0 : (n_queries <= 64 ? 1 : (n_queries <= 128 ? 2 : 3));
+}
+static uint32_t bf16_tile_rows(uint32_t n_queries) {
+    const int v = bf16_variant(n_queries);
+    return v == 2 ? 128 : 256;
+}
+
 template <int METRIC, int MODE>
 static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const float* d_norm2, const Bf16Scratch& s,
                              uint32_t tile_step, hipStream_t st) {
-    const int variant = n_queries <= 32 ? 0 : (n_queries <= 64 ? 1 : (n_queries <= 128 ? 2 : 3));
+    const int variant = bf16_variant(n_queries);
     const uint32_t BM = variant == 0 ? 32 : (variant == 1 ? 64 : (variant == 2 ? 128 : 256));
-    const uint32_t BN = variant <= 1 ? 256 : 128;
+    const uint32_t BN = bf16_tile_rows(n_queries);
     const uint32_t q_tiles = (n_queries + BM - 1) / BM;
     const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
     const uint32_t pass_tiles = (n_row_tiles + tile_step - 1) / tile_step;
@@ -321,7 +330,7 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const float*
     if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
     else if (variant == 1) TRAG_LAUNCH_BF16(2, 1, 4);  // 64 x 256
     else if (variant == 2) TRAG_LAUNCH_BF16(2, 2, 2);  // 128 x 128
-    else TRAG_LAUNCH_BF16(2, 4, 2);                    // 256 x 128, eight waves (two per SIMD)
+    else TRAG_LAUNCH_BF16(4, 2, 4);                    // 256 x 256, eight waves (two per SIMD)
 #undef TRAG_LAUNCH_BF16
 }
 
@@ -335,7 +344,7 @@ static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArg
     const uint32_t step = bf16_sample_step(a.n_rows, need);
     launch_gemm_bf16<METRIC, 0>(n_queries, a, d_norm2, s, step, st);
     // 64-row tiles the sample pass wrote maxima for (its last 128/256-row tile may be partial)
-    const uint32_t BN = n_queries <= 64 ? 256 : 128;
+    const uint32_t BN = bf16_tile_rows(n_queries);
     const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
     const uint32_t pass_tiles = (n_row_tiles + step - 1) / step;
     const uint32_t n_tile64 = pass_tiles * (BN / 32);  // maxima per 32 rows; every sampled workgroup writes all of its own
