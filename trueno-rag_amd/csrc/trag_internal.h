@@ -76,6 +76,7 @@ struct Bf16Scratch {
     uint32_t* tmax;      // [queries][tmax_stride]: tile maxima of the sample pass
     size_t tmax_stride;
     uint32_t* cand;      // [queries][CAND_CAP]
+    uint32_t* ckeys;     // [queries][CAND_CAP]: exact ordered keys of the candidates
 };
 
 constexpr uint32_t ST_OVERFLOW = 2;     // more candidates than the final sort holds: repeat exactly

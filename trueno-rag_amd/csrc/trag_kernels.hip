@@ -597,6 +597,70 @@ __device__ float exact_score_row(const float* __restrict__ v, const float* __res
 }
 
 
+// Exact re-score of a batch's candidate rows with the scan's staging: a wave takes 64
+// candidates, brings their rows in as 64 x 32 tiles through its private LDS image
+// (coalesced 16-byte loads along each row) and every lane sums its own row left to
+// right. One thread per row straight from memory thrashes the vector cache (64 rows
+// x 3 KB per wave) and took 168 us for 256 queries x ~250 rows of 768 floats.
+// grid (queries, CAND_CAP / 256); writes the ordered exact key of candidate i of
+// query y to out_keys[y * CAND_CAP + i].
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+rescore_kernel(const float* __restrict__ corpus, const float* __restrict__ Q, uint32_t n_rows, uint32_t d,
+               const SearchCtl* __restrict__ ctls, const uint32_t* __restrict__ cand,
+               uint32_t* __restrict__ out_keys) {
+    constexpr int CW = 32, STRIDE = CW + 4;
+    __shared__ __attribute__((aligned(16))) float tiles[4][64 * STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t y = blockIdx.x;
+    const SearchCtl* ctl = ctls + y;
+    uint32_t C = ctl->cand_count;
+    if (C > CAND_CAP) C = CAND_CAP;
+    const uint32_t base = blockIdx.y * 256u + (uint32_t)wid * 64u;
+    if (base >= C) return;  // tiles are private to a wave: no workgroup barrier below
+    const uint32_t* cq = cand + (size_t)y * CAND_CAP;
+    const float* __restrict__ q = Q + (size_t)y * d;
+    float* tile = tiles[wid];
+    const int lrow = lane >> 3, lcol = lane & 7;
+    const float* rptr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t ci = min(base + (uint32_t)(i * 8 + lrow), C - 1u);
+        rptr[i] = corpus + (size_t)min(cq[ci], n_rows - 1u) * d;
+    }
+    const uint32_t d4 = d >> 2, n_chunks = (d + CW - 1) / CW;
+    v4f pre[8];
+    auto issue = [&](uint32_t c) {
+        const uint32_t col4 = min(c * 8u + (uint32_t)lcol, d4 - 1u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pre[i] = reinterpret_cast<const v4f*>(rptr[i])[col4];
+    };
+    issue(0);
+    float acc0 = 0.0f, acc1 = 0.0f;
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<v4f*>(&tile[(i * 8 + lrow) * STRIDE + lcol * 4]) = pre[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (c + 1 < n_chunks) issue(c + 1);
+        const float* __restrict__ qc = q + c * CW;
+        const float* myrow = tile + lane * STRIDE;
+        const uint32_t len = min((uint32_t)CW, d - c * CW);
+        for (uint32_t j = 0; j < len / 4; ++j) {
+            const v4f x = *reinterpret_cast<const v4f*>(myrow + j * 4);
+            accum<METRIC>(qc[j * 4 + 0], x.x, acc0, acc1);
+            accum<METRIC>(qc[j * 4 + 1], x.y, acc0, acc1);
+            accum<METRIC>(qc[j * 4 + 2], x.z, acc0, acc1);
+            accum<METRIC>(qc[j * 4 + 3], x.w, acc0, acc1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t i = base + (uint32_t)lane;
+    if (i < C) out_keys[(size_t)y * CAND_CAP + i] = score_key(finish_score<METRIC>(acc0, acc1, ctl->na));
+}
+
 // Streaming / batched modes: every row left behind has an approximate score
 // <= t (the select threshold) and approximate and exact scores differ by at
 // most eps, so the exact top-k is final when its last member clears t + eps.
@@ -640,7 +704,8 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
              const uint32_t* __restrict__ keys, const uint32_t* __restrict__ cand,
              uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
              uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_status,
-             size_t keys_stride, uint32_t out_stride, int use_count) {
+             size_t keys_stride, uint32_t out_stride, int use_count,
+             const uint32_t* __restrict__ pre_keys = nullptr) {
     __shared__ unsigned long long sk[CAND_CAP];
     const int tid = threadIdx.x;
     {   // blockIdx.x = query of a batch (a single query launches one workgroup)
@@ -649,6 +714,7 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
         ctl += y;
         keys += (size_t)y * keys_stride;
         cand += (size_t)y * CAND_CAP;
+        if (pre_keys) pre_keys += (size_t)y * CAND_CAP;  // exact keys from rescore_kernel, by candidate
         out_rows += (size_t)y * out_stride;
         out_scores += (size_t)y * out_stride;
         out_n += y;
@@ -669,7 +735,8 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
             const uint32_t row = cand[i];
             uint32_t skey;
             if (RESCORE)
-                skey = score_key(exact_score_row<METRIC>(corpus + (size_t)row * d, q, d, na));
+                skey = pre_keys ? pre_keys[i]
+                                : score_key(exact_score_row<METRIC>(corpus + (size_t)row * d, q, d, na));
             else
                 skey = keys[row];
             v = rank_key(skey, row);
@@ -1412,10 +1479,17 @@ hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanA
 hipError_t launch_bf16_finish(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const Bf16Scratch& s,
                               uint32_t live, uint32_t out_stride, uint32_t* d_out_rows, float* d_out_scores,
                               uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
-#define TRAG_BF16_FINAL(METRIC)                                                                           \
-    hipLaunchKernelGGL((final_kernel<METRIC, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus, d_Q,   \
-                       a.n_rows, a.dim, live, s.ctls, (const uint32_t*)nullptr, s.cand, d_out_rows,       \
-                       d_out_scores, d_out_n, d_status, (size_t)0, out_stride, 3)
+    const bool gather = (a.dim & 3u) == 0u;  // the staged re-score needs 16-byte row pieces
+#define TRAG_BF16_FINAL(METRIC)                                                                            \
+    do {                                                                                                   \
+        if (gather)                                                                                        \
+            hipLaunchKernelGGL(rescore_kernel<METRIC>, dim3(n_queries, CAND_CAP / 256), dim3(256), 0, st,  \
+                               a.corpus, d_Q, a.n_rows, a.dim, s.ctls, s.cand, s.ckeys);                   \
+        hipLaunchKernelGGL((final_kernel<METRIC, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus,     \
+                           d_Q, a.n_rows, a.dim, live, s.ctls, (const uint32_t*)nullptr, s.cand,           \
+                           d_out_rows, d_out_scores, d_out_n, d_status, (size_t)0, out_stride, 3,          \
+                           gather ? (const uint32_t*)s.ckeys : (const uint32_t*)nullptr);                  \
+    } while (0)
     if (a.metric == TRAG_COSINE) TRAG_BF16_FINAL(0);
     else if (a.metric == TRAG_EUCLIDEAN) TRAG_BF16_FINAL(1);
     else TRAG_BF16_FINAL(2);
