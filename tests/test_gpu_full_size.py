@@ -83,3 +83,33 @@ def test_large_corpus_properties(trag, oracle, n, d):
         assert r3[:3].tolist() == planted, (mode, r3, planted)
         assert s3[0] == s3[1] == s3[2] == np.float32(oracle.cosine(q, q))
         assert r3[3:].tolist() == [int(x) for x in rows if int(x) not in planted][:7]
+
+
+@pytest.mark.parametrize("n,d,B,seed", [(1_000_000, 768, 256, 1003), (1_250_000, 384, 1000, 1004)])
+def test_batch_configs_against_oracle(trag, oracle, n, d, B, seed):
+    """C3 (1M x 768, 256 queries) and C4's per-GPU shard (1.25M x 384, 1000 queries): every
+    batch path returns the oracle's rows and score bits; all queries are compared between
+    paths, a sample of them against the oracle."""
+    store = _store(trag, d, n)
+    store.fill_synthetic(n, seed)
+    corpus = oracle.synth_rows(seed, 0, n, d)
+    Q = oracle.synth_rows(seed + 100, 0, B, d)
+    results = {}
+    for mode in (0, 3, 4):                     # auto (bf16 prefilter), f32 matrix cores, bf16 forced
+        store.set_scan_mode(mode)
+        results[mode] = store.search_batch_rows(Q, 10)
+        st = store.last_stats()
+        assert st["mode_used"] == (4 if mode == 0 else mode)
+        assert st["fallbacks"] <= 2
+    for mode in (3, 4):
+        assert np.array_equal(results[0][0], results[mode][0])
+        assert results[0][1].tobytes() == results[mode][1].tobytes()
+    rows, scores, cnt = results[0]
+    assert cnt.tolist() == [10] * B
+    for b in list(range(6)) + [B - 1]:
+        er, es = oracle.search(corpus, Q[b], 10, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"batch config n={n} q={b}")
+    # eight of them through one multi-query exact pass
+    store.set_scan_mode(EXACT)
+    r8, s8, _ = store.search_batch_rows(Q[:8], 10)
+    assert np.array_equal(r8, rows[:8]) and s8.tobytes() == scores[:8].tobytes()
