@@ -59,7 +59,7 @@ typedef enum trag_scan_mode {
     TRAG_SCAN_BF16 = 4    /* query batches: a bf16 matrix-core pass picks, per query, every row
                              that can be in the top k (rigorous error bound), no score matrix is
                              written, and those rows are scored exactly in f32 (dim % 64 == 0);
-                             AUTO prefers it to TRAG_SCAN_MFMA for large corpora */
+                             AUTO uses it from 4 queries up on large corpora */
 } trag_scan_mode;
 
 /* VectorStoreConfig, src/index.rs:283-307 (the hnsw_* fields are never read by

@@ -668,12 +668,15 @@ def test_bf16_auto_and_limits(trag, oracle):
     corpus = store.read_rows(0, n)
     Q = oracle.synth_rows(78, 0, 12, d)
     rows, scores, cnt = store.search_batch_rows(Q, 10)
-    assert store.last_stats()["mode_used"] == BF16          # AUTO: above 8 queries, large corpus
+    assert store.last_stats()["mode_used"] == BF16          # AUTO: from 4 queries up, large corpus
     for b in range(12):
         er, es = oracle.search(corpus, Q[b], 10, 0)
         assert_same_ranking(rows[b], scores[b], er, es, f"auto bf16 {b}")
-    store.search_batch_rows(Q[:8], 10)
-    assert store.last_stats()["mode_used"] == EXACT         # 2..8 queries: one exact pass
+    r4, s4, _ = store.search_batch_rows(Q[:4], 10)
+    assert store.last_stats()["mode_used"] == BF16
+    assert np.array_equal(r4, rows[:4]) and s4.tobytes() == scores[:4].tobytes()
+    store.search_batch_rows(Q[:3], 10)
+    assert store.last_stats()["mode_used"] == EXACT         # 2..3 queries: one exact multi-query pass
     store.search_batch_rows(Q, 300)
     assert store.last_stats()["mode_used"] == MFMA          # k too large for the candidate lists
     # clustered scores: thousands of rows within 2 eps of the k-th best overflow the lists -> exact repeat

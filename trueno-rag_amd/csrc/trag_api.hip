@@ -283,12 +283,14 @@ trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
     return TRAG_OK;
 }
 
-// The bf16 prefilter serves batches above 8 queries on corpora large enough for its
-// sample pass to be meaningful; k must leave room in the candidate lists.
+// The bf16 prefilter serves batches from 4 queries up on corpora large enough for its
+// sample pass to be meaningful; k must leave room in the candidate lists. Its 9/8
+// corpus reads cost about as much as a 3-query exact pass and less than a 4-query
+// one (10M x 384: 2.50 ms against 2.57 / 2.69 / 3.47 ms for 3 / 4 / 8 queries).
 bool use_bf16_path(const trag_store* s, uint32_t mode, uint32_t nq, uint32_t k) {
     if (!bf16_supports(s->cfg.dim, s->cfg.metric) || s->n_rows < 65536 || k > 256) return false;
     if (mode == TRAG_SCAN_BF16) return true;
-    return mode == TRAG_SCAN_AUTO && nq > 8;
+    return mode == TRAG_SCAN_AUTO && nq >= 4;
 }
 
 // Batches go to the matrix cores when the mode asks for it, or by default above
