@@ -9,7 +9,7 @@ There is no CPU fallback: every search goes through libtrag.so and its HIP
 kernels, and loading fails loudly when the library is missing.
 """
 from ._abi import lib, lib_path, TragError, DimensionMismatch, InvalidConfig  # noqa: F401
-from .index import VectorStore, VectorStoreConfig, DistanceMetric, Chunk, ChunkId  # noqa: F401
+from .index import VectorStore, VectorStoreConfig, DistanceMetric, ScanMode, Chunk, ChunkId  # noqa: F401
 from .sparse import BM25Index  # noqa: F401
 from .embed import MockEmbedder, EmbeddingConfig, EmptyDocument, QueryError  # noqa: F401
 from .persist import PersistedIndex, PersistedChunk, IndexServer  # noqa: F401
@@ -19,5 +19,5 @@ from .retrieve import (DenseRetriever, HybridRetriever, HybridRetrieverConfig,  
                        RetrievalResult)
 
 __all__ = ["lib", "lib_path", "TragError", "DimensionMismatch", "InvalidConfig", "VectorStore",
-           "VectorStoreConfig", "DistanceMetric", "Chunk", "ChunkId", "BM25Index", "MockEmbedder", "EmbeddingConfig", "EmptyDocument", "QueryError", "PersistedIndex", "PersistedChunk", "IndexServer", "FusionStrategy",
+           "VectorStoreConfig", "DistanceMetric", "ScanMode", "Chunk", "ChunkId", "BM25Index", "MockEmbedder", "EmbeddingConfig", "EmptyDocument", "QueryError", "PersistedIndex", "PersistedChunk", "IndexServer", "FusionStrategy",
            "LexicalReranker", "NoOpReranker", "DenseRetriever", "HybridRetriever", "HybridRetrieverConfig", "RetrievalResult"]

@@ -18,6 +18,16 @@ class DistanceMetric(enum.IntEnum):
     DotProduct = 2
 
 
+class ScanMode(enum.IntEnum):
+    """trag_scan_mode of include/trag.h (no counterpart in the reference: results are the
+    same in every mode, only the route to them differs)."""
+    Auto = 0
+    Exact = 1
+    Stream = 2
+    Mfma = 3
+    Bf16Prefilter = 4
+
+
 @dataclass
 class VectorStoreConfig:
     """src/index.rs:283-307. The hnsw_* fields exist for API parity; like the
