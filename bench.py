@@ -195,13 +195,15 @@ def main():
         scan_avg_ms = scan_ms / max(scan_launches, 1)
         algo_bytes = float(n_local) * d * 4.0  # bytes of corpus one scan launch must read
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
-        flops = 2.0 * B * n_local * d
+        passes = (B + 255) // 256 if mode_used in (3, 4) else (B + 7) // 8 if B > 1 else 1  # scan launches per step
+        b_launch = B / passes                                   # queries served by one scan launch
+        flops = 2.0 * b_launch * n_local * d
         tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
         # which roofline binds: 2*B*N*d flops over N*d*4 bytes against the peak of the matrix
         # pipe the path uses (f32 157.3 TF: B >= 40; bf16 prefilter 2500 TF: B >= 625) and 8 TB/s
         bf16 = mode_used == 4
         mfma_peak = 2500.0 if bf16 else 157.3
-        mfma_bound = mode_used in (3, 4) and B / 2.0 >= mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
+        mfma_bound = mode_used in (3, 4) and b_launch / 2.0 >= mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         result = {
             "metric": "queries/sec, brute-force cosine top-10 over N x d fp32 (achieved HBM GB/s in roofline)",
             "value": args.steps * B / elapsed,
@@ -241,7 +243,8 @@ def main():
             sparse_info["search_ms_alone"] = 1e3 * (time.perf_counter() - t0) / 20
             result["config"]["sparse"] = sparse_info
         result["roofline"].update({"kernel": "scan (corpus pass)", "kernel_avg_ms": scan_avg_ms,
-                                   "launches_timed": scan_launches, "algorithmic_bytes_per_launch": algo_bytes,
+                                   "launches_timed": scan_launches, "queries_per_launch": b_launch,
+                                   "algorithmic_bytes_per_launch": algo_bytes,
                                    "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9})
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(store, Q, n_local, n_total, d, k, args.cpu_sample_rows,

@@ -21,6 +21,7 @@
 // With 2.5 PFLOP/s of dense bf16 the pass is bound by the HBM read of the f32
 // corpus (converted to bf16 on the way into LDS) up to several hundred queries.
 #include <algorithm>
+#include <cmath>
 
 #include "trag_device.h"
 #include "trag_internal.h"
@@ -303,11 +304,23 @@ bool bf16_supports(uint32_t dim, uint32_t metric) {
     return (dim % BF_K) == 0 && metric <= TRAG_DOT_PRODUCT;
 }
 
-// Corpus tiles per sampled tile: the sample must hold many more 64-row tiles
-// than the rows wanted, or its k-th tile maximum says little.
-uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need) {
+// Corpus tiles per sampled tile. The sample must hold many more 32-row groups than
+// the rows wanted, or its k-th maximum says little; and it must be dense enough
+// that the candidate lists stay short: a list holds about need * step * w rows,
+// w = the growth of the rank over a score interval of 2 eps near the top of the
+// corpus (for unit-norm rows with independent components the scores have
+// sigma = 1 / sqrt(d) and the top sits near 5 sigma: w = exp(10 eps sqrt(d)),
+// 2.2 at d = 384, 3.2 at 768, 32 at 4096). Clustered corpora grow faster; their
+// lists overflow and those queries are repeated exactly.
+uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
     const uint64_t n_tile64 = (n_rows + 63) / 64;
-    const uint64_t step = n_tile64 / (64ull * (need ? need : 1));
+    if (need == 0) need = 1;
+    uint64_t step = n_tile64 / (64ull * need);
+    const double fd = (double)dim;
+    const double eps = 0.00390625 * 1.002 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
+    const double w = std::exp(10.0 * eps * std::sqrt(fd));
+    const double by_list = 1024.0 / ((double)need * w);
+    if ((double)step > by_list) step = (uint64_t)by_list;
     return (uint32_t)(step < 1 ? 1 : (step > 8 ? 8 : step));
 }
 
@@ -348,7 +361,7 @@ static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArg
     const uint32_t padded = (n_queries + 255u) / 256u * 256u;
     hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min<uint32_t>(1024, (padded * a.dim / 4 + 255) / 256)),
                        dim3(256), 0, st, d_Q, n_queries, padded, a.dim, reinterpret_cast<__bf16*>(s.qb));
-    const uint32_t step = bf16_sample_step(a.n_rows, need);
+    const uint32_t step = bf16_sample_step(a.n_rows, need, a.dim);
     launch_gemm_bf16<METRIC, 0>(n_queries, a, d_norm2, s, step, st);
     // 64-row tiles the sample pass wrote maxima for (its last 128/256-row tile may be partial)
     const uint32_t BN = bf16_tile_rows(n_queries);

@@ -156,7 +156,7 @@ void launch_tau_select(const uint32_t* tmax, size_t tmax_stride, uint32_t n_tile
                        uint32_t n_queries, hipStream_t st);
 // bf16 prefilter (trag_bf16.hip) and its exact finish (trag_kernels.hip)
 bool bf16_supports(uint32_t dim, uint32_t metric);
-uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need);
+uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim);
 hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const float* d_norm2,
                             const Bf16Scratch& s, uint32_t need, uint32_t k, const float* d_vmax_sq,
                             hipStream_t st);
