@@ -690,3 +690,23 @@ def test_bf16_auto_and_limits(trag, oracle):
         er, es = oracle.search(c2, Q2[b], 10, 0)
         assert_same_ranking(rows[b], scores[b], er, es, f"clustered bf16 {b}")
     assert store2.last_stats()["fallbacks"] >= 1
+
+
+def test_bf16_clustered_corpus_switches_to_f32_matrix_cores(trag, oracle):
+    """Every query sits in a cluster of thousands of near-identical rows: the bf16 lists overflow for
+    the whole batch, the batch is repeated on the f32 matrix cores and AUTO remembers."""
+    d, rng = 128, np.random.default_rng(21)
+    centers = unit_rows(rng, 16, d)
+    corpus = np.repeat(centers, 5000, axis=0) + 2e-3 * rng.standard_normal((80_000, d)).astype(np.float32)
+    corpus = corpus.astype(np.float32)
+    store = make_store(trag, d, 0, 0)
+    store.insert_rows(corpus)
+    Q = (centers + 1e-3 * rng.standard_normal((16, d))).astype(np.float32)
+    rows, scores, _ = store.search_batch_rows(Q, 10)
+    st = store.last_stats()
+    assert st["mode_used"] == MFMA and st["fallbacks"] >= 2
+    for b in range(16):
+        er, es = oracle.search(corpus, Q[b], 10, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"clustered batch {b}")
+    store.search_batch_rows(Q, 10)
+    assert store.last_stats()["mode_used"] == MFMA          # learned: no second bf16 attempt

@@ -87,6 +87,7 @@ struct trag_store {
     void* m_zero_block = nullptr;
     uint64_t m_keys_cap = 0;
     const SearchCtl* last_ctl = nullptr;  // control block of the last query enqueued (diagnostics)
+    bool bf16_off = false;         // learned: this corpus overflows the bf16 prefilter's candidate lists
     bool full_select = false;      // learned: this corpus needs the multi-level select
     unsigned long long* d_sort = nullptr;  // large-k path: rank keys of every row, padded to 2^m
     unsigned long long sort_cap = 0;
@@ -290,7 +291,7 @@ trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
 bool use_bf16_path(const trag_store* s, uint32_t mode, uint32_t nq, uint32_t k) {
     if (!bf16_supports(s->cfg.dim, s->cfg.metric) || s->n_rows < 65536 || k > 256) return false;
     if (mode == TRAG_SCAN_BF16) return true;
-    return mode == TRAG_SCAN_AUTO && nq >= 4;
+    return mode == TRAG_SCAN_AUTO && nq >= 4 && !s->bf16_off;
 }
 
 // Batches go to the matrix cores when the mode asks for it, or by default above
@@ -697,6 +698,30 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     s->stats.fallbacks = 0;
+    // A corpus whose scores cluster (many rows within the bf16 bound of the k-th best)
+    // overflows the prefilter's lists for many queries at once: repeat the whole batch on
+    // the f32 matrix cores, whose bound is ~50 times tighter, and remember it for AUTO.
+    if (mode == TRAG_SCAN_BF16 && n_queries >= 8) {
+        uint32_t bad = 0;
+        for (uint32_t b = 0; b < n_queries; ++b) bad += status[b] != ST_OK;
+        if (bad > n_queries / 8 && use_batch_path(s, TRAG_SCAN_MFMA, n_queries)) {
+            if (s->cfg.scan_mode == TRAG_SCAN_AUTO) s->bf16_off = true;
+            mode = TRAG_SCAN_MFMA;
+            s->stats.fallbacks += bad;
+            ts = enqueue_search(s, s->d_q, n_queries, k, mode, s->d_out_rows, s->d_out_scores, s->d_out_n,
+                                s->d_out_status, st);
+            if (ts != TRAG_OK) return ts;
+            HIP_TRY(hipMemcpyAsync(out_rows, s->d_out_rows, (size_t)n_queries * k * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_scores, s->d_out_scores, (size_t)n_queries * k * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_n, s->d_out_n, (size_t)n_queries * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(status.data(), s->d_out_status, (size_t)n_queries * sizeof(uint32_t),
+                                   hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
     // Repeat what the fast paths could not finish. A crowded coarse bin
     // (ST_NEED_REFINE) needs the multi-level select, which is then remembered
     // for later queries on this handle; an uncertified or overflowing
