@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows (whole job)")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 f32 matrix cores, 4 bf16 prefilter + exact finish")
+    ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 f32 matrix cores, 4 bf16 prefilter + exact finish, 5 bf16 mirror")
+    ap.add_argument("--mirror", action="store_true",
+                    help="keep a bf16 copy of the corpus in HBM (1.5x memory): prefilter passes read half the bytes, "
+                         "results stay the exact f32 results")
     ap.add_argument("--batch", type=int, default=1, help="queries per step (2..8: one multi-query exact pass; above: matrix-core path)")
     ap.add_argument("--sparse-vocab", type=int, default=50000)
     ap.add_argument("--sparse-tokens", type=int, default=64)
@@ -80,6 +83,8 @@ def main():
     store = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, device=local, scan_mode=args.mode,
                                                   reserve_rows=n_local))
     store.fill_synthetic(n_local, seed, first_global_row=row0)
+    if args.mirror:
+        store.set_bf16_mirror(True)
 
     B = args.batch
     n_q = (args.steps + args.warmup) * B
@@ -160,7 +165,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    store.set_profiling(True)
+    # an event pair costs ~6 us of stream time: on sub-millisecond scans time every 4th launch only
+    store.set_profiling(0 if os.environ.get("TRAG_BENCH_NO_PROFILE") else (4 if args.steps >= 40 else 1))
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
@@ -193,9 +199,16 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         scan_avg_ms = scan_ms / max(scan_launches, 1)
-        algo_bytes = float(n_local) * d * 4.0  # bytes of corpus one scan launch must read
+        # bytes of corpus one scan launch must read: the f32 rows, or the bf16 mirror's when the pass reads that
+        from_mirror = args.mirror and mode_used in (4, 5)
+        algo_bytes = float(n_local) * d * (2.0 if from_mirror else 4.0)
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
-        passes = (B + 255) // 256 if mode_used in (3, 4) else (B + 7) // 8 if B > 1 else 1  # scan launches per step
+        if mode_used in (3, 4):     # scan launches per step
+            passes = (B + 255) // 256
+        elif mode_used == 5:
+            passes = B
+        else:
+            passes = (B + 7) // 8
         b_launch = B / passes                                   # queries served by one scan launch
         flops = 2.0 * b_launch * n_local * d
         tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
@@ -223,10 +236,12 @@ def main():
                        f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, cosine top-{k}",
                        "rows": n_total, "dim": d, "k": k, "batch": B, "metric": "cosine",
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
-                       "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma", 4: "bf16-prefilter"}[args.mode],
+                       "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma", 4: "bf16-prefilter", 5: "bf16-mirror"}[args.mode],
+                       "bf16_mirror": bool(args.mirror),
                        "path_used": {1: "exact scan (f32, reference order)", 2: "streaming scan + exact re-score",
                                      3: "f32 matrix cores + exact re-score",
-                                     4: "bf16 matrix-core prefilter + exact f32 scoring of candidates"
+                                     4: "bf16 matrix-core prefilter + exact f32 scoring of candidates",
+                                     5: "scan of the bf16 mirror + exact f32 scoring of the rows within its bound"
                                      }.get(mode_used, str(mode_used))},
             "roofline": ({"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s",
                           "frac": tflops / mfma_peak, "traffic": None, "flops_per_launch": flops}

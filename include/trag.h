@@ -56,10 +56,15 @@ typedef enum trag_scan_mode {
     TRAG_SCAN_MFMA = 3,   /* query batches as Q x D^T on the matrix cores + exact re-score
                              (dim % 32 == 0); AUTO picks it above 8 queries;
                              2..8 queries share one exact corpus pass */
-    TRAG_SCAN_BF16 = 4    /* query batches: a bf16 matrix-core pass picks, per query, every row
+    TRAG_SCAN_BF16 = 4,   /* query batches: a bf16 matrix-core pass picks, per query, every row
                              that can be in the top k (rigorous error bound), no score matrix is
                              written, and those rows are scored exactly in f32 (dim % 64 == 0);
                              AUTO uses it from 4 queries up on large corpora */
+    TRAG_SCAN_MIRROR = 5  /* needs the bf16 mirror (trag_store_set_bf16_mirror): single queries
+                             scan the mirror (half the bytes), the rows that can be in the top
+                             k under a rigorous bound are then scored exactly in f32; batches
+                             run as TRAG_SCAN_BF16 reading the mirror. AUTO does the same once
+                             the mirror exists. Without a mirror: as AUTO. */
 } trag_scan_mode;
 
 /* VectorStoreConfig, src/index.rs:283-307 (the hnsw_* fields are never read by
@@ -186,12 +191,21 @@ trag_status trag_merge_packed_device(const uint32_t *d_gathered, uint32_t n_list
                                      uint32_t n_queries, uint32_t k, uint32_t *d_out_rows,
                                      float *d_out_scores, uint32_t *d_out_n, void *hip_stream);
 
+/* Optional bf16 copy of the corpus in HBM (1.5 x the memory, dimension % 8 == 0),
+ * kept in step with insert / overwrite / fill. It halves the bytes a prefiltering
+ * pass reads; results stay the exact f32 results (see TRAG_SCAN_MIRROR). enabled
+ * != 0 builds it from the rows present, 0 frees it. Needs exclusive access like
+ * insert. No counterpart in the reference. */
+trag_status trag_store_set_bf16_mirror(trag_store *s, int enabled);
+int trag_store_has_bf16_mirror(const trag_store *s);
+
 /* Change the scan mode of later searches (trag_scan_mode). */
 trag_status trag_store_set_scan_mode(trag_store *s, uint32_t scan_mode);
 
 /* Scan-kernel timing with HIP events on the stream the kernel runs on. While
- * enabled, every scan launch is bracketed by an event pair (at most 4096 are
- * kept). trag_store_scan_time waits for the recorded events, returns their
+ * enabled, every enabled-th scan launch (1 = every launch) is bracketed by an
+ * event pair (at most 4096 are kept; an event pair costs about 6 us of stream
+ * time, which matters for sub-millisecond scans). trag_store_scan_time waits for the recorded events, returns their
  * summed duration and count, and clears them. */
 trag_status trag_store_set_profiling(trag_store *s, int enabled);
 trag_status trag_store_scan_time(trag_store *s, double *total_ms, uint32_t *launches);

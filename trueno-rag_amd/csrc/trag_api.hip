@@ -70,6 +70,7 @@ struct trag_store {
     std::vector<uint32_t> h_dead;  // host mirror
     float* d_vmax_sq = nullptr;    // 1 float
     float* d_norm2 = nullptr;      // cap_rows squared row norms (batched cosine epilogue)
+    uint16_t* d_mirror = nullptr;  // optional bf16 copy of d_rows (cap_rows x dim), kept in step with it
     BatchScratch batch{};
     Bf16Scratch bf16{};
     uint64_t bf16_tiles_cap = 0;   // tile maxima per query the bf16 scratch holds
@@ -88,7 +89,10 @@ struct trag_store {
     uint64_t m_keys_cap = 0;
     const SearchCtl* last_ctl = nullptr;  // control block of the last query enqueued (diagnostics)
     bool bf16_off = false;         // learned: this corpus overflows the bf16 prefilter's candidate lists
+    bool mirror_off = false;       // learned: single-query mirror scans keep falling back on this corpus
+    uint32_t mirror_tries = 0, mirror_fails = 0;
     bool full_select = false;      // learned: this corpus needs the multi-level select
+    uint32_t refine_calls = 0, select_calls = 0;  // calls that needed it / all calls, while it is not the plan
     unsigned long long* d_sort = nullptr;  // large-k path: rank keys of every row, padded to 2^m
     unsigned long long sort_cap = 0;
     // staging for the host-pointer entry points
@@ -104,6 +108,8 @@ struct trag_store {
     trag_search_stats stats{};
     // optional scan timing
     bool profiling = false;
+    uint32_t profile_every = 1;    // bracket every n-th scan launch with events
+    uint32_t profile_seen = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // created once, reused
     size_t ev_used = 0;
 };
@@ -133,7 +139,20 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
         (void)hipFree(ndead);
         return fail(TRAG_OOM, std::string("hipMalloc(row norms): ") + hipGetErrorString(e));
     }
+    uint16_t* nmirror = nullptr;
+    if (s->d_mirror) {
+        e = hipMalloc(&nmirror, row_bytes / 2);
+        if (e != hipSuccess) {
+            (void)hipFree(nrows);
+            (void)hipFree(ndead);
+            (void)hipFree(nnorm);
+            return fail(TRAG_OOM, std::string("hipMalloc(bf16 mirror): ") + hipGetErrorString(e));
+        }
+    }
     HIP_TRY(hipMemsetAsync(ndead, 0, dead_words * sizeof(uint32_t), s->stream));
+    if (s->n_rows && nmirror)
+        HIP_TRY(hipMemcpyAsync(nmirror, s->d_mirror, (size_t)s->n_rows * s->cfg.dim * sizeof(uint16_t),
+                               hipMemcpyDeviceToDevice, s->stream));
     if (s->n_rows) {
         HIP_TRY(hipMemcpyAsync(nnorm, s->d_norm2, (size_t)s->n_rows * sizeof(float),
                                hipMemcpyDeviceToDevice, s->stream));
@@ -146,6 +165,8 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_dead) (void)hipFree(s->d_dead);
     if (s->d_norm2) (void)hipFree(s->d_norm2);
+    if (s->d_mirror) (void)hipFree(s->d_mirror);
+    s->d_mirror = nmirror;
     s->d_rows = nrows;
     s->d_dead = ndead;
     s->d_norm2 = nnorm;
@@ -156,6 +177,7 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
 
 trag_status ensure_scratch(trag_store* s) {
     if (!s->scratch.cand) HIP_TRY(hipMalloc(&s->scratch.cand, CAND_CAP * sizeof(uint32_t)));
+    if (!s->scratch.ckeys) HIP_TRY(hipMalloc(&s->scratch.ckeys, CAND_CAP * sizeof(uint32_t)));
     if (s->keys_cap < s->cap_rows || !s->zero_block) {
         void* old[] = {s->scratch.keys, s->scratch.tmax, s->zero_block};
         for (void* p : old)
@@ -288,10 +310,24 @@ trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
 // sample pass to be meaningful; k must leave room in the candidate lists. Its 9/8
 // corpus reads cost about as much as a 3-query exact pass and less than a 4-query
 // one (10M x 384: 2.50 ms against 2.57 / 2.69 / 3.47 ms for 3 / 4 / 8 queries).
+// With the bf16 mirror the pass reads half the bytes (10M x 384: about 1.3 ms) and serves
+// batches from 2 queries up. AUTO leaves the prefilter alone where its candidate lists
+// would near their capacity (large dimensions: the bound grows with sqrt(d) in units of
+// the score spread).
 bool use_bf16_path(const trag_store* s, uint32_t mode, uint32_t nq, uint32_t k) {
     if (!bf16_supports(s->cfg.dim, s->cfg.metric) || s->n_rows < 65536 || k > 256) return false;
     if (mode == TRAG_SCAN_BF16) return true;
-    return mode == TRAG_SCAN_AUTO && nq >= 4 && !s->bf16_off;
+    if (mode == TRAG_SCAN_MIRROR) return s->d_mirror != nullptr && nq >= 2;
+    if (mode != TRAG_SCAN_AUTO || s->bf16_off) return false;
+    if (bf16_list_estimate(s->n_rows, k, s->cfg.dim) > 2048.0) return false;
+    return nq >= (s->d_mirror ? 2u : 4u);
+}
+
+// Single queries read the bf16 mirror when there is one (half the bytes of the exact scan).
+bool use_mirror_scan(const trag_store* s, uint32_t mode, uint32_t nq, uint32_t k) {
+    if (!s->d_mirror || nq != 1 || s->mirror_off) return false;
+    if (!mirror_scan_supports_dim(s->cfg.dim) || s->n_rows < 65536 || k > 256) return false;
+    return mode == TRAG_SCAN_AUTO || mode == TRAG_SCAN_MIRROR;
 }
 
 // Batches go to the matrix cores when the mode asks for it, or by default above
@@ -309,15 +345,18 @@ uint32_t pick_mode(const trag_store* s, uint32_t requested) {
     uint32_t mode = requested;
     // The exact-order scan measured faster than the streaming one on MI355X (it
     // needs no re-score), so it is the default for every dimension.
-    if (mode == TRAG_SCAN_AUTO || mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16) mode = TRAG_SCAN_EXACT;
+    if (mode == TRAG_SCAN_AUTO || mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16 || mode == TRAG_SCAN_MIRROR)
+        mode = TRAG_SCAN_EXACT;
     if (mode == TRAG_SCAN_STREAM && !stream_supports_dim(s->cfg.dim)) mode = TRAG_SCAN_EXACT;
     return mode;
 }
 
 uint32_t choose_mode(const trag_store* s, uint32_t n_queries, uint32_t k) {
     const uint32_t k_eff = (uint32_t)std::min<uint64_t>(k, s->n_live);
+    if (use_mirror_scan(s, s->cfg.scan_mode, n_queries, k_eff)) return TRAG_SCAN_MIRROR;
     if (use_bf16_path(s, s->cfg.scan_mode, n_queries, k_eff)) return TRAG_SCAN_BF16;
-    const uint32_t asked = s->cfg.scan_mode == TRAG_SCAN_BF16 ? (uint32_t)TRAG_SCAN_AUTO : s->cfg.scan_mode;
+    const uint32_t asked = (s->cfg.scan_mode == TRAG_SCAN_BF16 || s->cfg.scan_mode == TRAG_SCAN_MIRROR)
+                               ? (uint32_t)TRAG_SCAN_AUTO : s->cfg.scan_mode;
     if (use_batch_path(s, asked, n_queries)) return TRAG_SCAN_MFMA;
     return pick_mode(s, s->cfg.scan_mode);
 }
@@ -365,7 +404,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             const uint32_t nb = std::min<uint32_t>(BATCH_QUERIES, n_queries - b0);
             const float* Qb = d_queries + (size_t)b0 * s->cfg.dim;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (s->profiling && s->ev_used < 4096) {
+            if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
                 if (s->ev_used == s->ev_pool.size()) {
                     hipEvent_t a0, a1;
                     HIP_TRY(hipEventCreate(&a0));
@@ -377,7 +416,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
                 s->ev_used += 1;
                 HIP_TRY(hipEventRecord(e0, st));
             }
-            HIP_TRY(launch_bf16_scan(Qb, nb, a, s->d_norm2, s->bf16, k_eff, k_eff, s->d_vmax_sq, st));
+            HIP_TRY(launch_bf16_scan(Qb, nb, a, s->d_mirror, s->d_norm2, s->bf16, k_eff, k_eff, s->d_vmax_sq, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
             HIP_TRY(launch_bf16_finish(Qb, nb, a, s->bf16, live, k, d_out_rows + (size_t)b0 * k,
                                        d_out_scores + (size_t)b0 * k, d_out_n + b0,
@@ -396,7 +435,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             const uint32_t nb = std::min<uint32_t>(BATCH_QUERIES, n_queries - b0);
             const float* Qb = d_queries + (size_t)b0 * s->cfg.dim;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (s->profiling && s->ev_used < 4096) {
+            if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
                 if (s->ev_used == s->ev_pool.size()) {
                     hipEvent_t a0, a1;
                     HIP_TRY(hipEventCreate(&a0));
@@ -414,6 +453,43 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
                                         d_out_scores + (size_t)b0 * k, d_out_n + b0,
                                         d_status ? d_status + b0 : nullptr, st));
         }
+        s->stats.mode_used = mode;
+        return TRAG_OK;
+    }
+    if (mode == TRAG_SCAN_MIRROR) {
+        // one query at a time: scan of the bf16 mirror, then the one-workgroup prune + exact scoring
+        if (!s->d_mirror) return fail(TRAG_INVALID_CONFIG, "the bf16 mirror is not enabled on this store");
+        // one-workgroup form: some slack below the k-th key so that the coarse cut clears it;
+        // multi-level form: the k-th approximate key itself is resolved, then lowered by the bound
+        const uint32_t need_m = s->full_select ? k_eff
+                                               : (uint32_t)std::min<uint64_t>((uint64_t)k_eff + STREAM_SLACK, live);
+        ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+        for (uint32_t b = 0; b < n_queries; ++b) {
+            const float* q = d_queries + (size_t)b * s->cfg.dim;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
+                if (s->ev_used == s->ev_pool.size()) {
+                    hipEvent_t a0, a1;
+                    HIP_TRY(hipEventCreate(&a0));
+                    HIP_TRY(hipEventCreate(&a1));
+                    s->ev_pool.emplace_back(a0, a1);
+                }
+                e0 = s->ev_pool[s->ev_used].first;
+                e1 = s->ev_pool[s->ev_used].second;
+                s->ev_used += 1;
+                HIP_TRY(hipEventRecord(e0, st));
+            }
+            uint32_t n_waves = 0;
+            HIP_TRY(launch_scan_mirror(s->d_mirror, q, s->d_norm2, a, s->scratch, need_m, k_eff, s->d_vmax_sq,
+                                       &n_waves, st));
+            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(launch_select_mirror(q, a, s->scratch, s->full_select, live, need_m, k_eff, n_waves,
+                                         d_out_rows + (size_t)b * k, d_out_scores + (size_t)b * k, d_out_n + b,
+                                         d_status ? d_status + b : nullptr, st));
+            // (the one-workgroup prune clears the coarse histogram itself)
+            if (s->full_select) HIP_TRY(hipMemsetAsync(s->scratch.hist, 0, s->zero_bytes - 256, st));
+        }
+        s->last_ctl = s->scratch.ctl;
         s->stats.mode_used = mode;
         return TRAG_OK;
     }
@@ -435,7 +511,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     for (uint32_t b = 0; b < n_queries; ++b) {
         const float* q = d_queries + (size_t)b * s->cfg.dim;
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (s->profiling && s->ev_used < 4096) {
+        if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
             if (s->ev_used == s->ev_pool.size()) {
                 hipEvent_t a0, a1;
                 HIP_TRY(hipEventCreate(&a0));
@@ -495,7 +571,7 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
     *out = nullptr;
     if (cfg->dim == 0) return fail(TRAG_INVALID_CONFIG, "dimension must be positive");
     if (cfg->metric > TRAG_DOT_PRODUCT) return fail(TRAG_INVALID_CONFIG, "unknown metric");
-    if (cfg->scan_mode > TRAG_SCAN_BF16) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    if (cfg->scan_mode > TRAG_SCAN_MIRROR) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -528,8 +604,8 @@ void trag_store_destroy(trag_store* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->batch.qpad, s->batch.ctls,
-                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys, s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax, s->d_sort, s->scratch.cand, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
+    void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->d_mirror, s->batch.qpad, s->batch.ctls,
+                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys, s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax, s->d_sort, s->scratch.cand, s->scratch.ckeys, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
                     s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -569,6 +645,8 @@ trag_status trag_store_insert(trag_store* s, const float* rows, uint64_t n, uint
     float* dst = s->d_rows + (size_t)s->n_rows * dim;
     HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(launch_update_vmax(dst, n, dim, s->d_vmax_sq, s->d_norm2 + s->n_rows, s->stream));
+    if (s->d_mirror)
+        HIP_TRY(launch_to_bf16(dst, n * dim, s->d_mirror + (size_t)s->n_rows * dim, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->n_rows += n;
     s->n_live += n;
@@ -588,6 +666,7 @@ trag_status trag_store_overwrite(trag_store* s, uint32_t row, const float* vec, 
     float* dst = s->d_rows + (size_t)row * dim;
     HIP_TRY(hipMemcpyAsync(dst, vec, (size_t)dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(launch_update_vmax(dst, 1, dim, s->d_vmax_sq, s->d_norm2 + row, s->stream));
+    if (s->d_mirror) HIP_TRY(launch_to_bf16(dst, dim, s->d_mirror + (size_t)row * dim, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return TRAG_OK;
 }
@@ -620,6 +699,8 @@ trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
     float* dst = s->d_rows + (size_t)s->n_rows * s->cfg.dim;
     hipError_t e = launch_fill_synthetic(dst, first_global_row, n, s->cfg.dim, seed, d_norm, s->stream);
     if (e == hipSuccess) e = launch_update_vmax(dst, n, s->cfg.dim, s->d_vmax_sq, s->d_norm2 + s->n_rows, s->stream);
+    if (e == hipSuccess && s->d_mirror)
+        e = launch_to_bf16(dst, n * s->cfg.dim, s->d_mirror + (size_t)s->n_rows * s->cfg.dim, s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     (void)hipFree(d_norm);
     if (e != hipSuccess) return fail(TRAG_DEVICE_ERROR, std::string("fill_synthetic: ") + hipGetErrorString(e));
@@ -726,11 +807,15 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
     // (ST_NEED_REFINE) needs the multi-level select, which is then remembered
     // for later queries on this handle; an uncertified or overflowing
     // streaming / matrix-core result is repeated with the exact scan.
+    const bool was_full = s->full_select;
+    bool any_refine = false;
     for (uint32_t b = 0; b < n_queries; ++b) {
         uint32_t cur_mode = mode;
         for (int attempt = 0; attempt < 3 && status[b] != ST_OK; ++attempt) {
             if (status[b] == ST_NEED_REFINE) {
+                any_refine = true;
                 s->full_select = true;
+                // (a mirror scan is repeated as such: it has a multi-level form)
                 if (cur_mode == TRAG_SCAN_MFMA || cur_mode == TRAG_SCAN_BF16) cur_mode = TRAG_SCAN_EXACT;
             } else {
                 s->stats.fallbacks += 1;
@@ -751,6 +836,22 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
         if (status[b] != ST_OK)
             return fail(TRAG_DEVICE_ERROR, "search could not be completed (status " +
                                                std::to_string(status[b]) + ")");
+    }
+    // One odd query (a zero vector: every cosine ties) must not slow the handle down for
+    // good: the multi-level select becomes the plan once at least 4 calls, and at least
+    // half of all calls so far, needed it.
+    if (!was_full) {
+        s->select_calls += 1;
+        if (any_refine) s->refine_calls += 1;
+        s->full_select = s->refine_calls >= 4 && s->refine_calls * 2 >= s->select_calls;
+    }
+    if (mode == TRAG_SCAN_MIRROR) {
+        // a corpus whose scores crowd within the mirror's bound keeps sending queries back to
+        // the exact scan (each costs a mirror pass extra): AUTO gives the mirror scan up then
+        s->mirror_tries += n_queries;
+        s->mirror_fails += s->stats.fallbacks;
+        if (s->cfg.scan_mode == TRAG_SCAN_AUTO && s->mirror_tries >= 16 && s->mirror_fails * 2 > s->mirror_tries)
+            s->mirror_off = true;
     }
     s->stats.mode_used = mode;
     if (mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16) {
@@ -775,16 +876,49 @@ trag_status trag_store_search(trag_store* s, const float* query, uint32_t dim, u
 
 trag_status trag_store_set_scan_mode(trag_store* s, uint32_t scan_mode) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
-    if (scan_mode > TRAG_SCAN_BF16) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
+    if (scan_mode > TRAG_SCAN_MIRROR) return fail(TRAG_INVALID_CONFIG, "unknown scan mode");
     std::lock_guard<std::mutex> lk(s->mu);
     s->cfg.scan_mode = scan_mode;
     return TRAG_OK;
 }
 
+trag_status trag_store_set_bf16_mirror(trag_store* s, int enabled) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (!enabled) {
+        if (s->d_mirror) {
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            HIP_TRY(hipDeviceSynchronize());
+            (void)hipFree(s->d_mirror);
+            s->d_mirror = nullptr;
+        }
+        return TRAG_OK;
+    }
+    if (s->d_mirror) return TRAG_OK;
+    if (s->cfg.dim % 8u) return fail(TRAG_UNSUPPORTED, "the bf16 mirror needs a dimension that is a multiple of 8");
+    const uint64_t cap = std::max<uint64_t>(s->cap_rows, 64);
+    HIP_TRY(hipMalloc(&s->d_mirror, (size_t)cap * s->cfg.dim * sizeof(uint16_t)));
+    if (s->cap_rows == 0) {
+        // nothing stored yet: grow_rows allocates the real mirror with the first rows
+        trag_status ts = grow_rows(s, 64);
+        if (ts != TRAG_OK) return ts;
+    }
+    if (s->n_rows) HIP_TRY(launch_to_bf16(s->d_rows, s->n_rows * s->cfg.dim, s->d_mirror, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->mirror_off = false;
+    s->mirror_tries = s->mirror_fails = 0;
+    return TRAG_OK;
+}
+
+int trag_store_has_bf16_mirror(const trag_store* s) { return s && s->d_mirror ? 1 : 0; }
+
 trag_status trag_store_set_profiling(trag_store* s, int enabled) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
     s->profiling = enabled != 0;
+    s->profile_every = enabled > 1 ? (uint32_t)enabled : 1u;
+    s->profile_seen = 0;
     s->ev_used = 0;
     return TRAG_OK;
 }

@@ -7,8 +7,8 @@
 //      per query the k-th largest tile maximum A_k of the sample is a score that
 //      at least k live rows reach approximately;
 //   2. every approximate score is within eps of the reference's f32 score
-//      (bf16 rounding of both operands, 2^-9 relative each, plus f32
-//      accumulation; bound below), so the exact k-th best is >= A_k - eps and
+//      (bf16 rounding of both operands, 2^-8 relative each, plus f32
+//      accumulation; bound in trag_device.h), so the exact k-th best is >= A_k - eps and
 //      every row of the exact top k has an approximate score >= A_k - 2 eps;
 //   3. the full GEMM pass appends exactly those rows to the query's candidate
 //      list (no score matrix is written: the pass reads the corpus once and
@@ -90,9 +90,13 @@ __global__ void shift_threshold_kernel(SearchCtl* __restrict__ ctls, uint32_t n_
 // MODE 1: full pass, appends rows whose approximate score reaches thr[query].
 // METRIC: 0 cosine, 1 Euclidean, 2 dot product.
 // ---------------------------------------------------------------------------
-template <int METRIC, int TM, int WGM, int WGN, int MODE>
+// MIR: the corpus operand comes from the bf16 mirror (half the bytes, no conversion);
+// the mirror holds exactly the values the conversion below produces, so both forms of
+// the pass compute the same accumulators.
+template <int METRIC, int TM, int WGM, int WGN, int MODE, bool MIR>
 __global__ void __launch_bounds__(64 * WGM * WGN)
-gemm_bf16_kernel(const float* __restrict__ corpus, const __bf16* __restrict__ Qb,
+gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mirror,
+                 const __bf16* __restrict__ Qb,
                  const float* __restrict__ norm2, const uint32_t* __restrict__ dead, uint32_t n_rows,
                  uint32_t d, uint32_t n_queries, uint32_t q_tiles, uint32_t tile_step,
                  SearchCtl* __restrict__ ctls, const float* __restrict__ thr,
@@ -102,7 +106,7 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const __bf16* __restrict__ Qb
     constexpr int BM = 32 * TM * WGM;   // queries per workgroup tile
     constexpr int BN = 64 * WGN;        // corpus rows per workgroup tile
     constexpr int NLA = BM * 8 / NT;    // 16-byte chunks of the query tile per thread and step
-    constexpr int NLB = BN * 16 / NT;   // 16-byte chunks (4 f32) of the corpus tile per thread and step
+    constexpr int NLB = MIR ? BN * 8 / NT : BN * 16 / NT;  // 16-byte chunks (8 bf16 / 4 f32) of the corpus tile per thread and step
     __shared__ __attribute__((aligned(16))) uint32_t As[BM * BF_LD];
     __shared__ __attribute__((aligned(16))) uint32_t Bs[BN * BF_LD];
     __shared__ __attribute__((aligned(16))) float qs_s[BM];  // MODE 1: the queries' thresholds
@@ -123,7 +127,7 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const __bf16* __restrict__ Qb
 
     const uint32_t nk = d / BF_K;
     const u32x4* aptr[NLA];
-    const float* bptr[NLB];
+    const char* bptr[NLB];
     int a_off[NLA], b_off[NLB];
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
@@ -133,29 +137,39 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const __bf16* __restrict__ Qb
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
-        const int c = tid + NT * i, row = c >> 4, col = c & 15;
+        const int c = tid + NT * i, row = MIR ? c >> 3 : c >> 4, col = MIR ? c & 7 : c & 15;
         const uint32_t r = min(n0 + (uint32_t)row, n_rows - 1u);
-        bptr[i] = corpus + (size_t)r * d + col * 4;
-        b_off[i] = row * BF_LD + col * 2;
+        if (MIR) {
+            bptr[i] = reinterpret_cast<const char*>(mirror + (size_t)r * d + col * 8);
+            b_off[i] = row * BF_LD + col * 4;
+        } else {
+            bptr[i] = reinterpret_cast<const char*>(corpus + (size_t)r * d + col * 4);
+            b_off[i] = row * BF_LD + col * 2;
+        }
     }
     // PF steps of operand loads are kept in flight in registers: with one or two waves per
     // SIMD a single step in flight leaves the pass bound by HBM latency, not bandwidth
     u32x4 ra[PF][NLA];
-    v4f rb[PF][NLB];
+    u32x4 rb[PF][NLB];  // MIR: 8 bf16; else the bits of 4 f32
     auto prefetch = [&](int slot, uint32_t kt) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) ra[slot][i] = aptr[i][kt * (BF_K / 8)];
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
-            rb[slot][i] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(bptr[i] + (size_t)kt * BF_K));
+            rb[slot][i] = __builtin_nontemporal_load(
+                reinterpret_cast<const u32x4*>(bptr[i] + (size_t)kt * (MIR ? BF_K * 2 : BF_K * 4)));
     };
     auto stage = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) *reinterpret_cast<u32x4*>(&As[a_off[i]]) = ra[slot][i];
 #pragma unroll
         for (int i = 0; i < NLB; ++i) {
-            const bf16x4 h = __builtin_convertvector(rb[slot][i], bf16x4);
-            *reinterpret_cast<u32x2*>(&Bs[b_off[i]]) = __builtin_bit_cast(u32x2, h);
+            if (MIR) {
+                *reinterpret_cast<u32x4*>(&Bs[b_off[i]]) = rb[slot][i];
+            } else {
+                const bf16x4 h = __builtin_convertvector(__builtin_bit_cast(v4f, rb[slot][i]), bf16x4);
+                *reinterpret_cast<u32x2*>(&Bs[b_off[i]]) = __builtin_bit_cast(u32x2, h);
+            }
         }
     };
 #pragma unroll
@@ -310,14 +324,14 @@ bool bf16_supports(uint32_t dim, uint32_t metric) {
 // w = the growth of the rank over a score interval of 2 eps near the top of the
 // corpus (for unit-norm rows with independent components the scores have
 // sigma = 1 / sqrt(d) and the top sits near 5 sigma: w = exp(10 eps sqrt(d)),
-// 2.2 at d = 384, 3.2 at 768, 32 at 4096). Clustered corpora grow faster; their
+// 4.8 at d = 384, 9.5 at 768, ~390 at 4096). Clustered corpora grow faster; their
 // lists overflow and those queries are repeated exactly.
 uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
     const uint64_t n_tile64 = (n_rows + 63) / 64;
     if (need == 0) need = 1;
     uint64_t step = n_tile64 / (64ull * need);
     const double fd = (double)dim;
-    const double eps = 0.00390625 * 1.002 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
+    const double eps = 0.0078125 * 1.003 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
     const double w = std::exp(10.0 * eps * std::sqrt(fd));
     const double by_list = 1024.0 / ((double)need * w);
     if ((double)step > by_list) step = (uint64_t)by_list;
@@ -333,9 +347,9 @@ static uint32_t bf16_tile_rows(uint32_t n_queries) {
     return v == 2 ? 128 : 256;
 }
 
-template <int METRIC, int MODE>
-static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const float* d_norm2, const Bf16Scratch& s,
-                             uint32_t tile_step, hipStream_t st) {
+template <int METRIC, int MODE, bool MIR>
+static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
+                             const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
     const int variant = bf16_variant(n_queries);
     const uint32_t BM = variant == 0 ? 32 : (variant == 1 ? 64 : (variant == 2 ? 128 : 256));
     const uint32_t BN = bf16_tile_rows(n_queries);
@@ -344,9 +358,9 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const float*
     const uint32_t pass_tiles = (n_row_tiles + tile_step - 1) / tile_step;
     const uint32_t grid = ((pass_tiles + 7) / 8) * q_tiles * 8;
 #define TRAG_LAUNCH_BF16(TM, WGM, WGN)                                                                       \
-    hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, TM, WGM, WGN, MODE>), dim3(grid), dim3(64 * WGM * WGN), 0, st, \
-                       a.corpus, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, a.dim,       \
-                       n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand)
+    hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, TM, WGM, WGN, MODE, MIR>), dim3(grid), dim3(64 * WGM * WGN), 0, \
+                       st, a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, \
+                       a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand)
     if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
     else if (variant == 1) TRAG_LAUNCH_BF16(2, 1, 4);  // 64 x 256
     else if (variant == 2) TRAG_LAUNCH_BF16(2, 2, 2);  // 128 x 128
@@ -355,14 +369,14 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const float*
 }
 
 // prep (norms, control blocks) is done by the caller with launch_batch_prep.
-template <int METRIC>
-static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const float* d_norm2,
-                             const Bf16Scratch& s, uint32_t need, hipStream_t st) {
+template <int METRIC, bool MIR>
+static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+                             const float* d_norm2, const Bf16Scratch& s, uint32_t need, hipStream_t st) {
     const uint32_t padded = (n_queries + 255u) / 256u * 256u;
     hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min<uint32_t>(1024, (padded * a.dim / 4 + 255) / 256)),
                        dim3(256), 0, st, d_Q, n_queries, padded, a.dim, reinterpret_cast<__bf16*>(s.qb));
     const uint32_t step = bf16_sample_step(a.n_rows, need, a.dim);
-    launch_gemm_bf16<METRIC, 0>(n_queries, a, d_norm2, s, step, st);
+    launch_gemm_bf16<METRIC, 0, MIR>(n_queries, a, d_mirror, d_norm2, s, step, st);
     // 64-row tiles the sample pass wrote maxima for (its last 128/256-row tile may be partial)
     const uint32_t BN = bf16_tile_rows(n_queries);
     const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
@@ -371,18 +385,34 @@ static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArg
     launch_tau_select(s.tmax, s.tmax_stride, n_tile64, s.ctls, n_queries, st);
     hipLaunchKernelGGL(shift_threshold_kernel<METRIC>, dim3((n_queries + 255) / 256), dim3(256), 0, st, s.ctls,
                        n_queries, a.dim, s.thr);
-    launch_gemm_bf16<METRIC, 1>(n_queries, a, d_norm2, s, 1, st);
+    launch_gemm_bf16<METRIC, 1, MIR>(n_queries, a, d_mirror, d_norm2, s, 1, st);
 }
 
-hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const float* d_norm2,
-                            const Bf16Scratch& s, uint32_t need, uint32_t k, const float* d_vmax_sq,
-                            hipStream_t st) {
+// d_mirror != nullptr: the passes read the bf16 mirror instead of the f32 corpus.
+hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+                            const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
+                            const float* d_vmax_sq, hipStream_t st) {
     hipError_t e = launch_batch_prep(d_Q, n_queries, a.dim, s.ctls, need, k, d_vmax_sq, st);
     if (e != hipSuccess) return e;
-    if (a.metric == TRAG_COSINE) bf16_scan_metric<0>(d_Q, n_queries, a, d_norm2, s, need, st);
-    else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1>(d_Q, n_queries, a, d_norm2, s, need, st);
-    else bf16_scan_metric<2>(d_Q, n_queries, a, d_norm2, s, need, st);
+    if (d_mirror) {
+        if (a.metric == TRAG_COSINE) bf16_scan_metric<0, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+        else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+        else bf16_scan_metric<2, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+    } else {
+        if (a.metric == TRAG_COSINE) bf16_scan_metric<0, false>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+        else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1, false>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+        else bf16_scan_metric<2, false>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+    }
     return hipGetLastError();
+}
+
+// Rows a query's candidate list is expected to hold on a corpus of independent
+// components (see bf16_sample_step); AUTO avoids the prefilter when it nears the list size.
+double bf16_list_estimate(uint64_t n_rows, uint32_t need, uint32_t dim) {
+    const double fd = (double)dim;
+    const double eps = 0.0078125 * 1.003 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
+    return (double)(need ? need : 1) * (double)bf16_sample_step(n_rows, need, dim) *
+           std::exp(10.0 * eps * std::sqrt(fd));
 }
 
 }  // namespace trag

@@ -45,12 +45,29 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // bf16 prefilter: largest |approximate - reference| of a score, as a multiple of
-// the scale ||q|| * ||v|| (cosine: of 1): both operands rounded to bf16
-// (2 * 2^-9 + 2^-18), d f32 accumulation steps of unknown rounding (2^-22 each),
-// and the rounding of the reference's own sequential sum and norms ((2d + 64) * 2^-24).
+// the scale ||q|| * ||v|| (cosine: of 1). bf16 keeps 8 significant bits, so rounding
+// to nearest moves a value by at most 2^-8 of its magnitude; with both operands
+// rounded, Cauchy-Schwarz gives |sum q'v' - sum qv| <= (2 * 2^-8 + 2^-16) ||q|| ||v||.
+// Added to it: d f32 accumulation steps of unknown rounding inside the matrix cores
+// (2^-22 each) and the rounding of the reference's own sequential sum and norms
+// ((2d + 64) * 2^-24).
 __device__ __forceinline__ float bf16_unit_eps(uint32_t d) {
     const float fd = (float)d;
-    return (0.00390625f * 1.002f + fd * 2.3841858e-07f * 1.01f + (2.0f * fd + 64.0f) * 5.9604645e-08f) * 1.01f;
+    return (0.0078125f * 1.003f + fd * 2.3841858e-07f * 1.01f + (2.0f * fd + 64.0f) * 5.9604645e-08f) * 1.01f;
+}
+
+// Single-query scan of the bf16 mirror: only the corpus is rounded (the query stays
+// f32 and the products are accumulated in f32): 2^-8 ||q|| ||v|| from the rounding,
+// plus the f32 summation error of both the approximate and the reference sum.
+// METRIC 0 cosine and 2 dot product: in score space; 1 Euclidean: in score space too
+// (| ||q - v'|| - ||q - v|| | <= ||v' - v|| <= 2^-8 ||v||).
+template <int METRIC>
+__device__ __forceinline__ float mirror_eps(uint32_t d, float na, float vmax) {
+    const float r = 0.00390625f * 1.003f;
+    const float f = (2.0f * (float)d + 64.0f) * 5.9604645e-08f * 1.01f;
+    if (METRIC == 0) return (r + f) * 1.01f + 1e-30f;
+    if (METRIC == 2) return (r + f) * na * vmax * 1.01f + 1e-30f;
+    return (r * vmax + f * (na + vmax)) * 1.01f + 1e-20f;
 }
 
 // The same bound in the key space of each metric (0 cosine: score; 2 dot

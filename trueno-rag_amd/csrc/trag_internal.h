@@ -53,6 +53,7 @@ struct Scratch {
     uint32_t* hist;      // HIST_LEVELS * HIST_BINS
     uint32_t* wmax;      // WMAX_CAP: largest key each scan wave saw (not an accumulator)
     uint32_t* cand;      // CAND_CAP row indices
+    uint32_t* ckeys;     // CAND_CAP exact ordered keys of the candidates (mirror scan, multi-level form)
     uint32_t* keys;      // capacity rows, ordered 32-bit keys (0 = removed row)
     uint32_t* tmax;      // capacity rows / 64: largest key of each 64-row tile
 };
@@ -157,9 +158,20 @@ void launch_tau_select(const uint32_t* tmax, size_t tmax_stride, uint32_t n_tile
 // bf16 prefilter (trag_bf16.hip) and its exact finish (trag_kernels.hip)
 bool bf16_supports(uint32_t dim, uint32_t metric);
 uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim);
-hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const float* d_norm2,
-                            const Bf16Scratch& s, uint32_t need, uint32_t k, const float* d_vmax_sq,
-                            hipStream_t st);
+hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+                            const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
+                            const float* d_vmax_sq, hipStream_t st);
+double bf16_list_estimate(uint64_t n_rows, uint32_t need, uint32_t dim);
+// bf16 mirror of the corpus (trag_mirror.hip) and the stages after its scan (trag_kernels.hip)
+hipError_t launch_to_bf16(const float* d_src, uint64_t n_floats, uint16_t* d_dst, hipStream_t st);
+bool mirror_scan_supports_dim(uint32_t dim);
+hipError_t launch_scan_mirror(const uint16_t* d_mirror, const float* d_q, const float* d_norm2, const ScanArgs& a,
+                              const Scratch& s, uint32_t need, uint32_t k, const float* d_vmax_sq,
+                              uint32_t* n_waves, hipStream_t st);
+hipError_t launch_select_mirror(const float* d_q, const ScanArgs& a, const Scratch& s, bool multi_level,
+                                uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
+                                uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
+                                uint32_t* d_status, hipStream_t st);
 hipError_t launch_bf16_finish(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const Bf16Scratch& s,
                               uint32_t live, uint32_t out_stride, uint32_t* d_out_rows, float* d_out_scores,
                               uint32_t* d_out_n, uint32_t* d_status, hipStream_t st);

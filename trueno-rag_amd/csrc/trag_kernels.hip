@@ -669,7 +669,8 @@ rescore_kernel(const float* __restrict__ corpus, const float* __restrict__ Q, ui
 // most eps, so the exact top-k is final when its last member clears t + eps.
 // key_mode: 0 keys are approximate scores of the streaming / f32 matrix-core pass;
 // 2 keys of the f32 matrix-core Euclidean pass (negated squared distance);
-// 3 keys of the bf16 prefilter (Euclidean: negated squared distance).
+// 3 keys of the bf16 prefilter (Euclidean: negated squared distance);
+// 4 keys of the single-query scan of the bf16 mirror (score space for every metric).
 template <int METRIC>
 __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float na, uint32_t t_key,
                             float ek, int key_mode = 0) {
@@ -681,7 +682,7 @@ __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float
     const float nsq = ctl->na_sq;
     if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f))) status = ST_UNCERTIFIED;
     const float t = t_key >= 0x007FFFFFu ? key_score(t_key) : -INFINITY;
-    if (METRIC == 1 && key_mode >= 2) {
+    if (METRIC == 1 && (key_mode == 2 || key_mode == 3)) {
         // Keys order -(||q||^2 + ||v||^2 - 2 q.v), an approximation of the negated SQUARED
         // distance with absolute error <= eps2. Every row left behind has approximate squared
         // distance >= T2 = -t; the exact k-th distance (squared, plus the rounding of the
@@ -694,6 +695,7 @@ __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float
         return status;
     }
     if (key_mode == 3) eps = bf16_eps<METRIC>(d, na, vmax);
+    else if (key_mode == 4) eps = mirror_eps<METRIC>(d, na, vmax);
     else if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
     else if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
     if (!(ek > t + eps) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
@@ -954,6 +956,345 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         ctl->levels = 1;
         ctl->status = status;
         if (out_status) *out_status = status;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// select_mirror: the one-workgroup stage after a scan of the bf16 mirror.
+//
+// keys[] hold APPROXIMATE scores, each within eps = mirror_eps of the reference's
+// f32 score (rows outside the bound's range carry +inf). The workgroup
+//   1. finds the coarse bin of the need-th best key (the cut); the rows at or above
+//      it are the first candidates (collected through wave and tile maxima, as
+//      select_final does);
+//   2. takes A = the k-th best approximate score among the candidates with a valid
+//      bound. k rows have an exact score >= A - eps, so every row of the exact top k
+//      has an approximate score >= T = A - 2 eps; when T lies below the cut the rows
+//      between T and the cut are collected too;
+//   3. the rows with approximate score >= T (plus the +inf rows) go to cand[]; they
+//      are scored from the f32 corpus in the reference's order by rescore_wave_kernel
+//      and ordered by mirror_final_kernel.
+// Crowded bins (ST_NEED_REFINE) send the query to the multi-level form below; a list
+// beyond its capacity or a query outside the bound's range is repeated with the exact scan.
+// ---------------------------------------------------------------------------
+// Mirror scan on a corpus whose scores crowd the coarse bins (the multi-level select is
+// the plan): after the radix levels, fix the need-th best approximate key A (need = k; an
+// early-resolved level gives a lower bound of it, which only admits more rows) and move the
+// threshold down to T = A - 2 eps: every row of the exact top k has an approximate score
+// >= T. compact_kernel then appends the rows at or above T, rescore_kernel / final_kernel
+// score them exactly. One workgroup of 256 threads.
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+mirror_threshold_kernel(SearchCtl* __restrict__ ctl, const uint32_t* __restrict__ hist, uint32_t d) {
+    __shared__ uint32_t sh[8];
+    uint32_t t_key;
+    if (ctl->resolved) {
+        t_key = ctl->t_key;
+    } else {
+        uint32_t b3, a3;
+        find_bin<256>(hist + 2 * HIST_BINS, ctl->need - ctl->above2, b3, a3, sh);
+        t_key = (ctl->b1 << 21) | (ctl->b2 << 10) | b3;
+    }
+    if (threadIdx.x == 0) {
+        const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq), nsq = ctl->na_sq;
+        const float eps = mirror_eps<METRIC>(d, na, vmax);
+        uint32_t T_key = 1u;  // outside the bound's range: every row is a candidate (overflows, repeated exactly)
+        if ((nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f)) && eps < INFINITY && t_key >= 0x007FFFFFu) {
+            const float T = key_score(t_key) - 2.02f * eps;
+            if (T == T && T > -INFINITY) T_key = score_key(T);
+        }
+        ctl->t_key = T_key;
+        ctl->resolved = 3;
+        ctl->cut_ties = 0;
+        ctl->cand_count = 0;
+        ctl->status = ST_OK;
+    }
+}
+
+constexpr uint32_t MIRROR_RESCORE = 2048;  // most rows scored exactly
+
+// Exact score of one row computed by a whole wave: lane l forms the product of
+// element 64c + l (rounded once, as the reference's x * y), then the products are
+// added strictly left to right through v_readlane, so the sum has the reference's
+// bits. Every lane returns the same value. All 64 lanes must call it.
+template <int METRIC>
+__device__ float exact_score_wave(const float* __restrict__ v, const float* __restrict__ q, uint32_t d,
+                                  float na, int lane) {
+    const uint32_t n_chunks = (d + 63u) / 64u;
+    auto load = [&](const float* __restrict__ p, uint32_t c) -> float {
+        const uint32_t j = c * 64u + (uint32_t)lane;
+        return (c < n_chunks && j < d) ? p[j] : 0.0f;
+    };
+    float acc0 = 0.0f, acc1 = 0.0f;
+    float x0 = load(v, 0), q0 = load(q, 0), x1 = load(v, 1), q1 = load(q, 1);
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const float x2 = load(v, c + 2), q2 = load(q, c + 2);
+        float p, p2 = 0.0f;
+        if (METRIC == 1) {
+            const float t = q0 - x0;
+            p = t * t;
+        } else {
+            p = q0 * x0;
+            if (METRIC == 0) p2 = x0 * x0;
+        }
+        const int b0 = __float_as_int(p), b1 = __float_as_int(p2);
+        const uint32_t len = min(64u, d - c * 64u);
+        if (len == 64u) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i) {
+                acc0 = acc0 + __int_as_float(__builtin_amdgcn_readlane(b0, i));
+                if (METRIC == 0) acc1 = acc1 + __int_as_float(__builtin_amdgcn_readlane(b1, i));
+            }
+        } else {
+            for (uint32_t i = 0; i < len; ++i) {
+                acc0 = acc0 + __int_as_float(__builtin_amdgcn_readlane(b0, (int)i));
+                if (METRIC == 0) acc1 = acc1 + __int_as_float(__builtin_amdgcn_readlane(b1, (int)i));
+            }
+        }
+        x0 = x1; q0 = q1; x1 = x2; q1 = q2;
+    }
+    return finish_score<METRIC>(acc0, acc1, na);
+}
+
+// One-workgroup prune after a mirror scan (see the header of this section): writes the
+// rows to score exactly to cand[], their number to ctl->cand_count, the lowered
+// threshold T to ctl->t_key and its verdict to ctl->status; zeroes the coarse histogram.
+template <int METRIC>
+__global__ void __launch_bounds__(1024)
+select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
+                     SearchCtl* __restrict__ ctl, uint32_t* __restrict__ hist,
+                     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
+                     const uint32_t* __restrict__ wmax, uint32_t* __restrict__ cand) {
+    __shared__ unsigned long long sk[CAND_CAP];
+    __shared__ uint32_t hit[CAND_CAP];
+    __shared__ uint32_t sh[24];
+    __shared__ uint32_t n_hit_sh, n_cand_sh, extra_sh, nf_sh, ns_sh, akey_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint32_t n_tiles = (n_rows + 63u) >> 6;
+    const uint32_t my_wmax = ((uint32_t)tid < n_waves && (uint32_t)tid < n_tiles) ? wmax[tid] : 0u;
+    const float na = ctl->na;
+    uint32_t b1, above1;
+    find_bin<1024>(hist, need, b1, above1, sh);
+    const uint32_t expect = above1 + hist[b1];
+    if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; extra_sh = 0; nf_sh = 0; ns_sh = 0; akey_sh = 0; }
+    __syncthreads();
+    // append the rows with lo <= key < hi to sk[] (through the wave maxima, then the tile
+    // maxima of the waves that pass, then the keys of the tiles that pass)
+    auto gather = [&](uint32_t lo, uint32_t hi) {
+        for (uint32_t w0 = 0; w0 < n_waves; w0 += 1024u) {
+            const uint32_t w = w0 + tid;
+            const uint32_t wm = w0 == 0 ? my_wmax : ((w < n_waves && w < n_tiles) ? wmax[w] : 0u);
+            if (wm >= lo) {
+                const uint32_t pos = atomicAdd(&n_hit_sh, 1u);
+                if (pos < CAND_CAP) hit[pos] = w;
+            }
+        }
+        __syncthreads();
+        const uint32_t nh = n_hit_sh < CAND_CAP ? n_hit_sh : CAND_CAP;
+        for (uint32_t h = wid; h < nh; h += 16u) {
+            const uint32_t w = hit[h];
+            for (uint32_t tb = 0; w + tb * n_waves < n_tiles; tb += 64u) {
+                const uint32_t tile = w + (tb + lane) * n_waves;
+                const uint32_t tm = tile < n_tiles ? tmax[tile] : 0u;
+                unsigned long long hits = __ballot(tm >= lo);
+                while (hits) {
+                    const uint32_t j = (uint32_t)__ffsll((long long)hits) - 1u;
+                    hits &= hits - 1ull;
+                    const uint32_t i = (w + (tb + j) * n_waves) * 64u + lane;
+                    const uint32_t key = i < n_rows ? keys[i] : 0u;
+                    const bool acc = key >= lo && key < hi;
+                    const unsigned long long m = __ballot(acc);
+                    if (m) {
+                        uint32_t pos0 = 0;
+                        if (lane == 0) pos0 = atomicAdd(&n_cand_sh, (uint32_t)__popcll(m));
+                        pos0 = __shfl(pos0, 0);
+                        if (acc) {
+                            const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            if (pos < CAND_CAP) sk[pos] = rank_key(key, i);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    uint32_t status = ST_OK, nS = 0, T_key = 1u, C = 0;
+    if (expect > CAND_CAP) {
+        status = ST_NEED_REFINE;
+    } else {
+        const uint32_t t_key = b1 << 21;
+        const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
+        const bool all_in = t_min == 1u;                 // every live row is a candidate
+        gather(t_min, 0xFFFFFFFFu);  // (+inf is the largest key a row can carry: 0xFF800000)
+        C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
+        // The k-th best approximate key by counting ranks (all threads read the same sk[j] at
+        // a time: an LDS broadcast); nothing needs sorting here.
+        const uint32_t INF_KEY = 0xFF800000u;  // rows without a valid bound: always scored exactly
+        {
+            unsigned long long mine[4];
+            uint32_t rank[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t i = (uint32_t)tid + 1024u * e;
+                mine[e] = i < C ? sk[i] : 0ull;
+                if (i < C && (uint32_t)(mine[e] >> 32) == INF_KEY) atomicAdd(&nf_sh, 1u);
+            }
+            const int live_e = C > 3072u ? 4 : (C > 2048u ? 3 : (C > 1024u ? 2 : 1));
+            for (uint32_t j = 0; j < C; ++j) {
+                const unsigned long long o = sk[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < live_e) rank[e] += o > mine[e] ? 1u : 0u;
+            }
+            __syncthreads();
+            const uint32_t nf = nf_sh;
+            if (nf + k <= C && k > 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t i = (uint32_t)tid + 1024u * e;
+                    if (i < C && rank[e] == nf + k - 1u) akey_sh = (uint32_t)(mine[e] >> 32);
+                }
+            }
+            __syncthreads();
+        }
+        const float vmax = sqrtf(ctl->vmax_sq);
+        const float eps = mirror_eps<METRIC>(d, na, vmax);
+        const float nsq = ctl->na_sq;
+        if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f)) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
+        if (akey_sh >= 0x007FFFFFu) {
+            const float T = key_score(akey_sh) - 2.02f * eps;
+            T_key = (T == T && T > -INFINITY) ? score_key(T) : 1u;
+            if (T_key < 1u) T_key = 1u;
+        } else if (!all_in) {
+            status = ST_UNCERTIFIED;  // fewer than k bounded rows above the cut
+        }
+        // T below the cut: the rows between T and the cut join the candidates (their keys are
+        // below every candidate so far: the k-th best key stands). The coarse histogram bounds
+        // their number before anything is gathered.
+        if (status == ST_OK && !all_in && T_key < t_min) {
+            const uint32_t cut2 = T_key >> 21;
+            if (b1 - cut2 > 64u) {
+                status = ST_UNCERTIFIED;
+            } else {
+                if (wid == 0) {
+                    const uint32_t bin = b1 - 1u - (uint32_t)lane;
+                    uint32_t h = (bin >= cut2 && bin < b1) ? hist[bin] : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
+                    if (lane == 0) { extra_sh = h; n_hit_sh = 0; }
+                }
+                __syncthreads();
+                if (C + extra_sh > CAND_CAP) {
+                    status = ST_OVERFLOW;
+                } else {
+                    gather(T_key, t_min);
+                    C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
+                }
+            }
+        }
+        if (status == ST_OK) {
+            for (uint32_t i = tid; i < C; i += 1024u) {
+                const unsigned long long v = sk[i];
+                if ((uint32_t)(v >> 32) >= T_key) {
+                    const uint32_t pos = atomicAdd(&ns_sh, 1u);
+                    if (pos < CAND_CAP) cand[pos] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
+                }
+            }
+        }
+        __syncthreads();
+        nS = ns_sh;
+        if (nS > MIRROR_RESCORE) { status = ST_OVERFLOW; nS = 0; }
+    }
+    // leave the accumulator clean for the next query's scan
+    for (uint32_t i = tid; i < HIST_BINS; i += 1024u) hist[i] = 0u;
+    if (tid == 0) {
+        ctl->cand_count = status == ST_OK ? nS : 0u;
+        ctl->expect = C;
+        ctl->t_key = T_key;
+        ctl->levels = 1;
+        ctl->status = status;
+    }
+}
+
+// Exact scores of the listed rows, one wave per row, spread over the whole GPU (a row of
+// 4096 floats takes one wave ~27 us: the sum is sequential by definition).
+// out_keys[i] = ordered key of the exact score of row cand[i], i < min(ctl->cand_count, CAND_CAP).
+template <int METRIC>
+__global__ void __launch_bounds__(256)
+rescore_wave_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows, uint32_t d,
+                    const SearchCtl* __restrict__ ctl, const uint32_t* __restrict__ cand,
+                    uint32_t* __restrict__ out_keys) {
+    const int lane = threadIdx.x & 63;
+    uint32_t C = ctl->cand_count;
+    if (C > CAND_CAP) C = CAND_CAP;
+    const float na = ctl->na;
+    const uint32_t n_w = gridDim.x * 4u;
+    for (uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6); i < C; i += n_w) {
+        const uint32_t row = min(cand[i], n_rows - 1u);
+        const float sc = exact_score_wave<METRIC>(corpus + (size_t)row * d, q, d, na, lane);
+        if (lane == 0) out_keys[i] = score_key(sc);
+    }
+}
+
+// Last stage after a mirror scan: order the exactly scored rows (rank by counting), write
+// the best k, confirm that the k-th clears the threshold by the bound (true by construction
+// when the bound holds), and reset what the next query accumulates into.
+template <int METRIC>
+__global__ void __launch_bounds__(1024)
+mirror_final_kernel(uint32_t d, uint32_t live, SearchCtl* __restrict__ ctl, const uint32_t* __restrict__ cand,
+                    const uint32_t* __restrict__ ckeys, uint32_t* __restrict__ out_rows,
+                    float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
+                    uint32_t* __restrict__ out_status) {
+    __shared__ unsigned long long sk[CAND_CAP];
+    __shared__ float ek_sh;
+    const int tid = threadIdx.x;
+    uint32_t status = ctl->status;
+    uint32_t C = ctl->cand_count;
+    if (C > CAND_CAP) { status = ST_OVERFLOW; C = 0; }
+    if (status != ST_OK) C = 0;
+    const uint32_t k = ctl->k;
+    const uint32_t n_out = k < C ? k : C;
+    unsigned long long mine[4];
+    uint32_t rank[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t i = (uint32_t)tid + 1024u * e;
+        mine[e] = i < C ? rank_key(ckeys[i], cand[i]) : 0ull;
+        if (i < C) sk[i] = mine[e];
+    }
+    if (tid == 0) ek_sh = 0.0f;
+    __syncthreads();
+    const int live_e = C > 3072u ? 4 : (C > 2048u ? 3 : (C > 1024u ? 2 : 1));
+    for (uint32_t j = 0; j < C; ++j) {
+        const unsigned long long o = sk[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e < live_e) rank[e] += o > mine[e] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t i = (uint32_t)tid + 1024u * e;
+        if (i < C && rank[e] < n_out) {
+            float sc = key_score((uint32_t)(mine[e] >> 32));
+            if (rank[e] == n_out - 1u) ek_sh = sc;
+            if (METRIC == 1 && sc == 0.0f) sc = -0.0f;  // -(sqrt(0)) in the reference
+            out_rows[rank[e]] = 0xFFFFFFFFu - (uint32_t)(mine[e] & 0xFFFFFFFFull);
+            out_scores[rank[e]] = sc;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (status == ST_OK && C < live && n_out > 0)
+            status = certify<METRIC>(ctl, d, ctl->na, ctl->t_key, ek_sh, 4);
+        *out_n = status == ST_OK ? n_out : 0u;
+        ctl->status = status;
+        if (out_status) *out_status = status;
+        // the fields a query accumulates into (the histograms were cleared by the stage before)
+        ctl->resolved = 0;
+        ctl->cand_count = 0;
+        ctl->cut_ties = 0;
+        ctl->tie_quota = 0;
+        ctl->b1 = ctl->above1 = ctl->b2 = ctl->above2 = ctl->above3 = 0;
     }
 }
 
@@ -1346,6 +1687,43 @@ hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratc
         select_final_dispatch<2>(d_q, a, s, rescore, live, need, k, n_waves, d_out_rows, d_out_scores, d_out_n, d_status, n_queries, m, out_stride, st);
         break;
     }
+    return hipGetLastError();
+}
+
+// Stages after a mirror scan. One-workgroup form: prune -> exact scores -> order.
+// Multi-level form (crowded score bins): radix levels -> threshold -> compact -> exact
+// scores -> order; the caller clears the histograms afterwards.
+hipError_t launch_select_mirror(const float* d_q, const ScanArgs& a, const Scratch& s, bool multi_level,
+                                uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
+                                uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
+                                uint32_t* d_status, hipStream_t st) {
+    const uint32_t rgrid = grid_for(a.n_rows, 256 * 16, 256);
+    const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
+    const uint32_t cgrid = grid_for(n_tiles, 256, 256);
+    if (multi_level) {
+        hipLaunchKernelGGL(refine_kernel<2>, dim3(rgrid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl, s.hist);
+        hipLaunchKernelGGL(refine_kernel<3>, dim3(rgrid), dim3(256), 0, st, s.keys, a.n_rows, s.ctl, s.hist);
+    }
+#define TRAG_MIRROR_STAGES(METRIC)                                                                         \
+    do {                                                                                                   \
+        if (multi_level) {                                                                                 \
+            hipLaunchKernelGGL(mirror_threshold_kernel<METRIC>, dim3(1), dim3(256), 0, st, s.ctl, s.hist,  \
+                               a.dim);                                                                     \
+            hipLaunchKernelGGL(compact_kernel, dim3(cgrid), dim3(256), 0, st, s.keys, s.tmax, a.n_rows,    \
+                               s.ctl, (const uint32_t*)nullptr, s.cand, (size_t)0, (size_t)0);             \
+        } else {                                                                                           \
+            hipLaunchKernelGGL(select_mirror_kernel<METRIC>, dim3(1), dim3(1024), 0, st, a.n_rows, a.dim,  \
+                               live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax, s.wmax, s.cand);     \
+        }                                                                                                  \
+        hipLaunchKernelGGL(rescore_wave_kernel<METRIC>, dim3(256), dim3(256), 0, st, a.corpus, d_q,        \
+                           a.n_rows, a.dim, s.ctl, s.cand, s.ckeys);                                       \
+        hipLaunchKernelGGL(mirror_final_kernel<METRIC>, dim3(1), dim3(1024), 0, st, a.dim, live, s.ctl,    \
+                           s.cand, s.ckeys, d_out_rows, d_out_scores, d_out_n, d_status);                  \
+    } while (0)
+    if (a.metric == TRAG_COSINE) TRAG_MIRROR_STAGES(0);
+    else if (a.metric == TRAG_EUCLIDEAN) TRAG_MIRROR_STAGES(1);
+    else TRAG_MIRROR_STAGES(2);
+#undef TRAG_MIRROR_STAGES
     return hipGetLastError();
 }
 

@@ -26,6 +26,7 @@ class ScanMode(enum.IntEnum):
     Stream = 2
     Mfma = 3
     Bf16Prefilter = 4
+    Mirror = 5
 
 
 @dataclass
@@ -181,8 +182,16 @@ class VectorStore:
     def set_scan_mode(self, mode: int) -> None:
         _abi.check(_abi.lib().trag_store_set_scan_mode(self._h, mode))
 
-    def set_profiling(self, enabled: bool) -> None:
-        _abi.check(_abi.lib().trag_store_set_profiling(self._h, 1 if enabled else 0))
+    def set_profiling(self, enabled) -> None:
+        """False/0 off, True/1 every scan launch, n > 1 every n-th scan launch."""
+        _abi.check(_abi.lib().trag_store_set_profiling(self._h, int(enabled)))
+
+    def set_bf16_mirror(self, enabled: bool) -> None:
+        """Build (or free) the bf16 copy of the corpus that AUTO / ScanMode.Mirror read."""
+        _abi.check(_abi.lib().trag_store_set_bf16_mirror(self._h, 1 if enabled else 0))
+
+    def has_bf16_mirror(self) -> bool:
+        return bool(_abi.lib().trag_store_has_bf16_mirror(self._h))
 
     def scan_time(self):
         """(total milliseconds, launches) of the scan kernels since profiling was enabled."""
