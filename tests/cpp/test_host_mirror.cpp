@@ -66,6 +66,20 @@ int main() {
         auto r = s.search({0.9f, 0.1f, 0.0f}, 10);
         EXPECT(r.size() == 3 && r[0].first == id1 && r[1].first == id3);
     }
+    {   // not in the reference: the optional bf16 copy never changes a result (small store: exact path)
+        VectorStore s = VectorStore::with_dimension(8);
+        s.set_bf16_mirror(true);
+        EXPECT(s.has_bf16_mirror());
+        Chunk c1 = chunk_with("a", {1, 0, 0, 0, 0, 0, 0, 0}), c2 = chunk_with("b", {0, 1, 0, 0, 0, 0, 0, 0});
+        ChunkId id2 = c2.id;
+        s.insert(c1); s.insert(c2);
+        auto r = s.search({0.1f, 0.9f, 0, 0, 0, 0, 0, 0}, 1);
+        EXPECT(r.size() == 1 && r[0].first == id2);
+        s.set_bf16_mirror(false);
+        EXPECT(!s.has_bf16_mirror());
+        VectorStore s3 = VectorStore::with_dimension(3);
+        try { s3.set_bf16_mirror(true); EXPECT(false); } catch (const std::exception&) {}
+    }
     {   // test_vector_store_search_top_k, :775-790
         VectorStore s = VectorStore::with_dimension(3);
         for (int i = 0; i < 10; ++i) s.insert(chunk_with("chunk", {(float)i, 0.0f, 0.0f}));

@@ -115,33 +115,51 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t last = n_rows - 1u;
 
+    // Two groups of U row-iterations ping-pong through registers: the loads of the next
+    // group (of this tile or of the wave's next tile) are in flight while the current one
+    // is reduced.
+    static_assert((ITERS / U) % 2 == 0, "groups per tile must pair up");
+    u32x4 xa[U][NV], xb[U][NV];
+    auto issue = [&](u32x4 (&x)[U][NV], uint32_t tile, int it0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t r = min(tile * 64u + (uint32_t)((it0 + u) * RPW + sub), last);
+            const u32x4* p = reinterpret_cast<const u32x4*>(mirror + (size_t)r * D) + gl;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) x[u][j] = __builtin_nontemporal_load(p + j * G);
+        }
+    };
+    float mine = 0.0f;
+    auto reduce = [&](const u32x4 (&x)[U][NV], int it0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) accum_piece<METRIC>(qlo[j], qhi[j], x[u][j], a0, a1);
+            a0 += a1;
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) a0 += __shfl_xor(a0, o);
+            if (it0 + u == gl) mine = a0;
+        }
+    };
     uint32_t wave_best = 0u;
-    for (uint32_t t = blockIdx.x * 4u + wid; t < n_tiles; t += n_waves) {
+    uint32_t t = blockIdx.x * 4u + wid;
+    if (t < n_tiles) issue(xa, t, 0);
+    for (; t < n_tiles; t += n_waves) {
         const uint32_t row0 = t * 64u;
-        float mine = 0.0f;
+        // this lane's row of the tile: its squared norm is fetched now and used after the loop
+        const uint32_t row = row0 + (uint32_t)(gl * RPW + sub);
+        float nb2 = 0.0f;
+        if (METRIC == 0) nb2 = norm2[min(row, last)];
 #pragma unroll 1
-        for (int it0 = 0; it0 < ITERS; it0 += U) {
-            u32x4 x[U][NV];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t r = min(row0 + (uint32_t)((it0 + u) * RPW + sub), last);
-                const u32x4* p = reinterpret_cast<const u32x4*>(mirror + (size_t)r * D) + gl;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) x[u][j] = __builtin_nontemporal_load(p + j * G);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-                for (int j = 0; j < NV; ++j) accum_piece<METRIC>(qlo[j], qhi[j], x[u][j], a0, a1);
-                a0 += a1;
-#pragma unroll
-                for (int o = G / 2; o > 0; o >>= 1) a0 += __shfl_xor(a0, o);
-                if (it0 + u == gl) mine = a0;
-            }
+        for (int it0 = 0; it0 < ITERS; it0 += 2 * U) {
+            issue(xb, t, it0 + U);
+            reduce(xa, it0);
+            if (it0 + 2 * U < ITERS) issue(xa, t, it0 + 2 * U);
+            else if (t + n_waves < n_tiles) issue(xa, t + n_waves, 0);
+            reduce(xb, it0 + U);
         }
         // this lane holds the sum of tile row gl*RPW + sub
-        const uint32_t row = row0 + (uint32_t)(gl * RPW + sub);
         uint32_t key = 0u;
         if (row < n_rows) {
             if (!row_is_dead(dead, row)) {
@@ -151,7 +169,6 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
                 float s;
                 bool ok = fabsf(mine) < INFINITY;
                 if (METRIC == 0) {
-                    const float nb2 = norm2[row];
                     ok = ok && (nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY));
                     const float nb = sqrtf(nb2);
                     s = (na == 0.0f || nb == 0.0f) ? 0.0f : mine / (na * nb);
@@ -200,7 +217,8 @@ static uint32_t launch_one(const uint16_t* mirror, const float* d_q, const float
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
                 &per_cu, scan_mirror_kernel<METRIC, G, NV, U>, 256, 0) != hipSuccess || per_cu < 1)
             per_cu = 2;
-        if (per_cu > 2) per_cu = 2;
+        // measured on MI355X (10M x 384): 1 workgroup per CU 6.28 TB/s, 2: 6.07, 4 and more: 6.0
+        if (per_cu > 1) per_cu = 1;
         if (hipGetDevice(&dev) == hipSuccess)
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         cap = (uint32_t)per_cu * (uint32_t)cus;
@@ -220,7 +238,7 @@ static uint32_t launch_metric(const uint16_t* mirror, const float* d_q, const fl
     switch (a.dim) {
         TRAG_MIRROR_CASE(128, 16, 1, 8);
         TRAG_MIRROR_CASE(256, 32, 1, 8);
-        TRAG_MIRROR_CASE(384, 16, 3, 4);
+        TRAG_MIRROR_CASE(384, 16, 3, 4);  // (8 lanes per row, or 2 / 8 rows in flight: within 2 %)
         TRAG_MIRROR_CASE(512, 64, 1, 8);
         TRAG_MIRROR_CASE(768, 32, 3, 4);
         TRAG_MIRROR_CASE(1024, 64, 2, 4);

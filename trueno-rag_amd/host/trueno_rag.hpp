@@ -157,6 +157,10 @@ class VectorStore {
     }
     size_t len() const { return (size_t)trag_store_len(h_); }
     bool is_empty() const { return len() == 0; }
+    // Not in the reference: keep a bf16 copy of the corpus in HBM (1.5 x the memory) that
+    // prefiltering passes read instead of the f32 rows; results stay the exact f32 results.
+    void set_bf16_mirror(bool enabled) { check(trag_store_set_bf16_mirror(h_, enabled ? 1 : 0)); }
+    bool has_bf16_mirror() const { return trag_store_has_bf16_mirror(h_) != 0; }
     trag_store* handle() const { return h_; }
 
   private:

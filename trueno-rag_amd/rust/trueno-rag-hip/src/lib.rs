@@ -19,6 +19,7 @@ extern "C" {
     fn trag_store_overwrite(s: *mut TragStore, row: u32, v: *const f32, dim: u32) -> i32;
     fn trag_store_remove(s: *mut TragStore, row: u32) -> i32;
     fn trag_store_len(s: *const TragStore) -> u64;
+    fn trag_store_set_bf16_mirror(s: *mut TragStore, enabled: i32) -> i32;
     fn trag_store_search(s: *mut TragStore, q: *const f32, dim: u32, k: u32,
                          rows: *mut u32, scores: *mut f32, n: *mut u32) -> i32;
     fn trag_store_search_batch(s: *mut TragStore, q: *const f32, nq: u32, dim: u32, k: u32,
@@ -107,6 +108,12 @@ impl GpuVectorStore {
     }
     pub fn len(&self) -> usize { unsafe { trag_store_len(self.h) as usize } }
     pub fn is_empty(&self) -> bool { self.len() == 0 }
+    /// Not in the reference: a bf16 copy of the corpus in HBM (1.5 x the memory) for the
+    /// prefiltering passes; search results stay the exact f32 results.
+    pub fn set_bf16_mirror(&mut self, enabled: bool) -> Result<()> {
+        let rc = unsafe { trag_store_set_bf16_mirror(self.h, enabled as i32) };
+        if rc != 0 { Err(err(rc, 0, 0)) } else { Ok(()) }
+    }
 }
 impl Drop for GpuVectorStore { fn drop(&mut self) { unsafe { trag_store_destroy(self.h) } } }
 
