@@ -710,3 +710,44 @@ def test_bf16_clustered_corpus_switches_to_f32_matrix_cores(trag, oracle):
         assert_same_ranking(rows[b], scores[b], er, es, f"clustered batch {b}")
     store.search_batch_rows(Q, 10)
     assert store.last_stats()["mode_used"] == MFMA          # learned: no second bf16 attempt
+
+
+def test_concurrent_searches_on_one_handle(trag, oracle):
+    """`search(&self)` is shared in the reference (src/index.rs:386): searches from several
+    threads on one store must be safe (the handle serialises them) and return what a single
+    thread gets; a second store searched at the same time must not disturb it."""
+    import threading
+    n, d = 30_000, 128
+    rng = np.random.default_rng(314)
+    corpus = unit_rows(rng, n, d)
+    store = make_store(trag, d)
+    store.insert_rows(corpus)
+    other = make_store(trag, d, 2)
+    other.insert_rows(corpus[:5000])
+    Q = unit_rows(rng, 24, d)
+    expect = [oracle.search(corpus, q, 10, 0) for q in Q]
+    expect_other = [oracle.search(corpus[:5000], q, 5, 2) for q in Q]
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for b in range(t, 24, 4):
+                    rows, scores = store.search_rows(Q[b], 10)
+                    assert_same_ranking(rows, scores, expect[b][0], expect[b][1], f"thread {t} query {b}")
+                    if t == 0:
+                        r2, s2 = other.search_rows(Q[b], 5)
+                        assert_same_ranking(r2, s2, expect_other[b][0], expect_other[b][1], f"other store {b}")
+                    if t == 1:   # batches interleave with single queries on the same handle
+                        rb, sb, _ = store.search_batch_rows(Q[b:b + 3], 10)
+                        for j in range(rb.shape[0]):
+                            assert_same_ranking(rb[j], sb[j], expect[b + j][0], expect[b + j][1], f"batch {b}+{j}")
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]

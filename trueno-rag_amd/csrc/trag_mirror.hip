@@ -82,8 +82,7 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
                    uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
                    SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys, uint32_t* __restrict__ tmax,
                    uint32_t* __restrict__ wmax, uint32_t* __restrict__ hist) {
-    constexpr int RPW = 64 / G;   // rows per wave iteration
-    constexpr int ITERS = G;      // iterations per 64-row tile
+    constexpr int ITERS = G;      // iterations per 64-row tile; iteration i takes rows i, G + i, 2G + i, ... of the tile
     constexpr int D16 = G * NV;   // 16-byte pieces per row
     constexpr uint32_t D = 8u * D16;
     static_assert(ITERS % U == 0, "unroll must divide the tile");
@@ -123,7 +122,7 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
     auto issue = [&](u32x4 (&x)[U][NV], uint32_t tile, int it0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t r = min(tile * 64u + (uint32_t)((it0 + u) * RPW + sub), last);
+            const uint32_t r = min(tile * 64u + (uint32_t)(sub * ITERS + it0 + u), last);
             const u32x4* p = reinterpret_cast<const u32x4*>(mirror + (size_t)r * D) + gl;
 #pragma unroll
             for (int j = 0; j < NV; ++j) x[u][j] = __builtin_nontemporal_load(p + j * G);
@@ -148,7 +147,7 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
     for (; t < n_tiles; t += n_waves) {
         const uint32_t row0 = t * 64u;
         // this lane's row of the tile: its squared norm is fetched now and used after the loop
-        const uint32_t row = row0 + (uint32_t)(gl * RPW + sub);
+        const uint32_t row = row0 + (uint32_t)(sub * ITERS + gl);  // = row0 + lane
         float nb2 = 0.0f;
         if (METRIC == 0) nb2 = norm2[min(row, last)];
 #pragma unroll 1
@@ -159,7 +158,7 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
             else if (t + n_waves < n_tiles) issue(xa, t + n_waves, 0);
             reduce(xb, it0 + U);
         }
-        // this lane holds the sum of tile row gl*RPW + sub
+        // this lane holds the sum of tile row sub*G + gl = its own lane index
         uint32_t key = 0u;
         if (row < n_rows) {
             if (!row_is_dead(dead, row)) {
