@@ -785,6 +785,78 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
 
 
 // ---------------------------------------------------------------------------
+// Candidate gather of the one-workgroup select stages (1024 threads): append every
+// row with lo <= key < hi to sk[] (as its rank key, or as its bare row index), counting
+// in *n_cand. A scan leaves three levels to descend: the best key of each scan wave
+// (wmax), of each 64-row tile (tmax; tile t was scanned by wave t % n_waves), and the
+// keys. Each level is one flat, fully parallel sweep -- every thread issues its
+// independent loads back to back, so a level costs about one memory round trip:
+//   waves that reach lo -> hit[];  their tiles that reach lo -> a tile list;  the 64
+//   keys of each listed tile.
+// The tile list lives in the upper half of sk[] (as 32-bit words), so this form needs
+// the candidates to stay within the lower half: callers use it when at most
+// CAND_CAP / 2 rows can qualify, and the wave-by-wave form below otherwise.
+// All 1024 threads must call it; ends with a barrier.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void gather_flat(uint32_t lo, uint32_t hi, bool rows_only, uint32_t n_rows,
+                                            uint32_t n_tiles, uint32_t n_waves, uint32_t my_wmax,
+                                            const uint32_t* __restrict__ wmax, const uint32_t* __restrict__ tmax,
+                                            const uint32_t* __restrict__ keys, unsigned long long* sk,
+                                            uint32_t* hit, uint32_t* n_hit, uint32_t* n_thit, uint32_t* n_cand) {
+    const uint32_t tid = threadIdx.x;
+    uint32_t* thit = reinterpret_cast<uint32_t*>(sk + CAND_CAP / 2);  // CAND_CAP words
+    for (uint32_t w0 = 0; w0 < n_waves; w0 += 1024u) {
+        const uint32_t w = w0 + tid;
+        const uint32_t wm = w0 == 0 ? my_wmax : ((w < n_waves && w < n_tiles) ? wmax[w] : 0u);
+        if (wm >= lo) {
+            const uint32_t pos = atomicAdd(n_hit, 1u);
+            if (pos < CAND_CAP) hit[pos] = w;
+        }
+    }
+    __syncthreads();
+    const uint32_t nh = *n_hit < CAND_CAP ? *n_hit : CAND_CAP;
+    const uint32_t tpw = (n_tiles + n_waves - 1u) / n_waves;  // tiles per scan wave
+    const uint32_t total = nh * tpw;
+    for (uint32_t i0 = 0; i0 < total; i0 += 4096u) {
+        uint32_t tile[4], tm[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t i = i0 + tid + 1024u * e;
+            const uint32_t h = i / tpw, j = i - h * tpw;
+            tile[e] = i < total ? hit[h] + j * n_waves : 0xFFFFFFFFu;
+            tm[e] = tile[e] < n_tiles ? tmax[tile[e]] : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (tm[e] >= lo) {
+                const uint32_t pos = atomicAdd(n_thit, 1u);
+                if (pos < CAND_CAP) thit[pos] = tile[e];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t nt = *n_thit < CAND_CAP ? *n_thit : CAND_CAP;
+    const uint32_t lane = tid & 63u;
+    for (uint32_t t0 = 0; t0 < nt; t0 += 64u) {  // 16 waves x 4 tiles per round
+        uint32_t row[4], key[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t ti = t0 + (tid >> 6) * 4u + e;
+            row[e] = ti < nt ? thit[ti] * 64u + lane : 0xFFFFFFFFu;
+            key[e] = row[e] < n_rows ? keys[row[e]] : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (key[e] >= lo && key[e] < hi) {
+                const uint32_t pos = atomicAdd(n_cand, 1u);
+                if (pos < CAND_CAP / 2) sk[pos] = rows_only ? (unsigned long long)row[e] : rank_key(key[e], row[e]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // select_final: the common case in ONE workgroup. The scan's histogram gives
 // the coarse bin that holds the need-th best key; when the rows at or above
 // that bin fit the sort they are collected through the two levels of tile
@@ -819,7 +891,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t hit[CAND_CAP];
     __shared__ uint32_t sh[24];
-    __shared__ uint32_t n_hit_sh, n_cand_sh;
+    __shared__ uint32_t n_hit_sh, n_cand_sh, n_thit_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     // independent of the threshold: this thread's share of the per-wave maxima
@@ -835,9 +907,13 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     } else {
         const uint32_t t_key = b1 << 21;
         const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
-        if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; }
+        if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; n_thit_sh = 0; }
         __syncthreads();
-        // scan waves whose best key reaches the threshold ...
+        if (expect <= CAND_CAP / 2) {
+            gather_flat(t_min, 0xFFFFFFFFu, RESCORE, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit,
+                        &n_hit_sh, &n_thit_sh, &n_cand_sh);
+        } else {
+        // (more rows than the flat form holds) scan waves whose best key reaches the threshold ...
         for (uint32_t w0 = 0; w0 < n_waves; w0 += 1024u) {
             const uint32_t w = w0 + tid;
             const uint32_t wm = w0 == 0 ? my_wmax : ((w < n_waves && w < n_tiles) ? wmax[w] : 0u);
@@ -875,6 +951,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
             }
         }
         __syncthreads();
+        }
         C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
         n_out = k < C ? k : C;
         float ek = 0.0f;  // score of the last returned row (thread 0)
@@ -1068,7 +1145,7 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t hit[CAND_CAP];
     __shared__ uint32_t sh[24];
-    __shared__ uint32_t n_hit_sh, n_cand_sh, extra_sh, nf_sh, ns_sh, akey_sh;
+    __shared__ uint32_t n_hit_sh, n_cand_sh, n_thit_sh, extra_sh, nf_sh, ns_sh, akey_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     const uint32_t my_wmax = ((uint32_t)tid < n_waves && (uint32_t)tid < n_tiles) ? wmax[tid] : 0u;
@@ -1076,11 +1153,16 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
     uint32_t b1, above1;
     find_bin<1024>(hist, need, b1, above1, sh);
     const uint32_t expect = above1 + hist[b1];
-    if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; extra_sh = 0; nf_sh = 0; ns_sh = 0; akey_sh = 0; }
+    if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; n_thit_sh = 0; extra_sh = 0; nf_sh = 0; ns_sh = 0; akey_sh = 0; }
     __syncthreads();
     // append the rows with lo <= key < hi to sk[] (through the wave maxima, then the tile
     // maxima of the waves that pass, then the keys of the tiles that pass)
-    auto gather = [&](uint32_t lo, uint32_t hi) {
+    auto gather = [&](uint32_t lo, uint32_t hi, uint32_t at_most) {
+        if (at_most <= CAND_CAP / 2) {  // at_most: bound of the candidate count after this call
+            gather_flat(lo, hi, false, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit, &n_hit_sh,
+                        &n_thit_sh, &n_cand_sh);
+            return;
+        }
         for (uint32_t w0 = 0; w0 < n_waves; w0 += 1024u) {
             const uint32_t w = w0 + tid;
             const uint32_t wm = w0 == 0 ? my_wmax : ((w < n_waves && w < n_tiles) ? wmax[w] : 0u);
@@ -1125,7 +1207,7 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
         const uint32_t t_key = b1 << 21;
         const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
         const bool all_in = t_min == 1u;                 // every live row is a candidate
-        gather(t_min, 0xFFFFFFFFu);  // (+inf is the largest key a row can carry: 0xFF800000)
+        gather(t_min, 0xFFFFFFFFu, expect);  // (+inf is the largest key a row can carry: 0xFF800000)
         C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
         // The k-th best approximate key by counting ranks (all threads read the same sk[j] at
         // a time: an LDS broadcast); nothing needs sorting here.
@@ -1181,13 +1263,13 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
                     uint32_t h = (bin >= cut2 && bin < b1) ? hist[bin] : 0u;
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
-                    if (lane == 0) { extra_sh = h; n_hit_sh = 0; }
+                    if (lane == 0) { extra_sh = h; n_hit_sh = 0; n_thit_sh = 0; }
                 }
                 __syncthreads();
                 if (C + extra_sh > CAND_CAP) {
                     status = ST_OVERFLOW;
                 } else {
-                    gather(T_key, t_min);
+                    gather(T_key, t_min, C + extra_sh);
                     C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
                 }
             }
