@@ -68,7 +68,8 @@ __device__ __forceinline__ float finish_score(float acc0, float acc1, float na) 
 // 256 release fences and a 256-thread select cost more than the launch boundary
 // they remove: step 0.278 ms vs 0.256 ms at 1M x 384, 2.357 vs 2.329 at 10M x 384.
 // ---------------------------------------------------------------------------
-template <int METRIC, int EX_CW /* chunk width in floats: 32 or 64 */, bool NT, int WPB /* waves per workgroup */>
+template <int METRIC, int EX_CW /* chunk width in floats: 32 or 64 */, bool NT, int WPB /* waves per workgroup */,
+          bool ROLL /* refill load by load instead of chunk by chunk */>
 __global__ void __launch_bounds__(WPB * 64)
 scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
                      const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
@@ -125,15 +126,30 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
         while (t < n_tiles) {
             float acc0 = 0.0f, acc1 = 0.0f;
             for (uint32_t c = 0; c < n_chunks; ++c) {
-                // stage chunk c (the reads of the previous chunk are older DS ops of this wave)
+                // Stage chunk c (the reads of the previous chunk are older DS ops of this wave) and
+                // refill. ROLL: as soon as load i of this chunk has landed and gone to LDS, load i of
+                // the next chunk (of this tile or of the wave's next tile; past the end: a clamped,
+                // harmless address) is issued into the same registers, so the wave keeps NLD loads in
+                // flight instead of draining to zero before it issues again (used for short rows only,
+                // see the launcher).
+                const bool same = c + 1 < n_chunks;
+                const uint32_t nt = same ? t : t + n_waves, nc = same ? c + 1 : 0u;
+                const uint32_t ncol4 = min(nc * (uint32_t)LPR + (uint32_t)lcol, d4 - 1u);
 #pragma unroll
-                for (int i = 0; i < NLD; ++i)
+                for (int i = 0; i < NLD; ++i) {
                     *reinterpret_cast<v4f*>(&tile[(i * RPL + lrow) * EX_STRIDE + lcol * 4]) = pre[i];
+                    if (ROLL) {
+                        const uint32_t r = min(nt * 64u + (uint32_t)(i * RPL + lrow), n_rows - 1u);
+                        const v4f* p = reinterpret_cast<const v4f*>(corpus + (size_t)r * d) + ncol4;
+                        pre[i] = NT ? __builtin_nontemporal_load(p) : *p;
+                    }
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                // prefetch the next chunk (of this tile or of the wave's next tile)
-                if (c + 1 < n_chunks) issue(t, c + 1);
-                else if (t + n_waves < n_tiles) issue(t + n_waves, 0);
+                if (!ROLL) {  // chunk by chunk: all loads of the next chunk after the staging
+                    if (same) issue(t, c + 1);
+                    else if (t + n_waves < n_tiles) issue(t + n_waves, 0);
+                }
                 const float* __restrict__ qc = q + c * EX_CW;
                 const float* myrow = tile + lane * EX_STRIDE;
                 const uint32_t len = min((uint32_t)EX_CW, d - c * EX_CW);
@@ -1584,9 +1600,16 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
                 (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         }
         const uint32_t grid = grid_for(n_tiles, 4, (uint32_t)n_cu);
-        hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4>), dim3(grid), dim3(256), 0, st,
-                           a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
-                           s.tmax, s.wmax, s.hist);
+        // load-by-load refill pays only for short rows (same run, MI355X: d = 128 +6 %, 384 -2 %,
+        // 768 / 1536 / 4096 within noise)
+        if (a.dim <= 256)
+            hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, true>), dim3(grid), dim3(256), 0, st,
+                               a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
+                               s.tmax, s.wmax, s.hist);
+        else
+            hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, false>), dim3(grid), dim3(256), 0, st,
+                               a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
+                               s.tmax, s.wmax, s.hist);
         return grid * 4u;
     } else {
         const uint32_t grid = grid_for(a.n_rows, 256, 256 * 8);
