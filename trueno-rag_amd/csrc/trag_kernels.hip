@@ -1591,7 +1591,8 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
         // One workgroup of 4 waves per CU, each wave with one 8 KB chunk in flight,
         // measured best on MI355X (10M x 384: 6.66 TB/s; 2 or 3 workgroups per CU 6.51 / 6.43,
         // one workgroup of 3 / 5 / 6 / 8 waves 6.35 / 6.51 / 6.50 / 6.47,
-        // 64-float chunks 6.44, default-policy instead of non-temporal loads 5.94).
+        // 64-float chunks 6.44 (with 2 / 3 waves per CU 5.93 / 6.26), default-policy instead of
+        // non-temporal loads 5.94).
         static int n_cu = 0;
         if (n_cu == 0) {
             int dev = 0;
