@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--hybrid", action="store_true",
                     help="hybrid step: dense top-50 + BM25 top-50 (synthetic documents) -> RRF(60) -> top-k on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the rocprofv3 counter pass that measures the scan kernel's HBM traffic")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     return ap.parse_args()
 
@@ -68,6 +70,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit(2)
     import torch.distributed as dist
+    # HBM traffic of the scan kernel from the hardware counters: a short copy of this very run
+    # under rocprofv3, started before this process touches the GPU
+    traffic = None
+    if world == 1 and not args.no_pmc and not args.hybrid and not os.environ.get("TRAG_BENCH_CHILD"):
+        traffic = pmc_traffic(args)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -257,6 +264,9 @@ def main():
                 bm25.search_ids(q_terms[i % len(q_terms)], cand)
             sparse_info["search_ms_alone"] = 1e3 * (time.perf_counter() - t0) / 20
             result["config"]["sparse"] = sparse_info
+        if traffic is not None:
+            result["roofline"]["traffic"] = traffic.pop("bytes_per_launch")
+            result["roofline"]["traffic_source"] = traffic
         result["roofline"].update({"kernel": "scan (corpus pass)", "kernel_avg_ms": scan_avg_ms,
                                    "launches_timed": scan_launches, "queries_per_launch": b_launch,
                                    "algorithmic_bytes_per_launch": algo_bytes,
@@ -317,6 +327,59 @@ def mirror_leg(store, args, Q, out_rows, out_scores, out_n, status, n_local, d, 
                           5: "scan of the bf16 mirror + exact f32 scoring"}.get(mode_used, str(mode_used)),
             "unfinished_queries": int((status[lo:] != 0).sum().item()),
             "identical_to_headline_results": same, "extra_hbm_bytes": bytes_launch}
+
+
+def pmc_traffic(args):
+    """FETCH_SIZE of the scan kernel, per launch, from a counters-only rocprofv3 pass over a
+    3-step copy of this run (its own process). FETCH_SIZE counts KiB at the L2's memory side;
+    on gfx950 it tallies the 128-byte requests of a coalesced 16-byte-per-lane stream at 64
+    bytes, so the byte count is 2 * 1024 * FETCH_SIZE. Returns None when the pass is not
+    possible (no rocprofv3, a failure, a timeout): the bench line then carries traffic null."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="trag_pmc_", dir="/tmp")
+    cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "-o", "p", "--",
+           sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-pmc", "--rows", str(args.rows), "--dim", str(args.dim), "--k", str(args.k),
+           "--mode", str(args.mode), "--batch", str(args.batch)] + (["--mirror"] if args.mirror else [])
+    env = dict(os.environ, TRAG_BENCH_CHILD="1", TMPDIR="/tmp")
+    try:
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                start_new_session=True)
+        try:
+            proc.wait(timeout=150)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+            return None
+        vals = {}
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                name = r.get("Kernel_Name", "")
+                if r.get("Counter_Name") != "FETCH_SIZE":
+                    continue
+                if ("scan_exact" in name or "scan_mirror" in name or "scan_stream" in name or "gemm_" in name):
+                    vals.setdefault(name.split("(")[0], []).append(float(r["Counter_Value"]))
+        if not vals:
+            return None
+        # the dominant scan kernel = the one that fetched most in total; drop its first launch (warm-up)
+        name, v = max(vals.items(), key=lambda kv: sum(kv[1]))
+        v = v[1:] if len(v) > 1 else v
+        kib = sum(v) / len(v)
+        return {"bytes_per_launch": 2.0 * 1024.0 * kib, "counter": "FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies "
+                "128-byte requests at 64 bytes)", "kernel": name.replace("void ", ""), "launches": len(v),
+                "tool": "rocprofv3 --pmc FETCH_SIZE, separate 3-step run of the same workload"}
+    except Exception:  # noqa: BLE001 -- the counter pass is optional evidence, never a reason to fail the bench
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def sparse_queries(n, vocab, n_terms, seed):
