@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--rows", type=int, default=10_000_000, help="corpus rows (whole job)")
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", choices=["cosine", "euclidean", "dot"], default="cosine",
+                    help="DistanceMetric of the store (the headline is cosine, the reference's default)")
     ap.add_argument("--mode", type=int, default=0, help="0 auto, 1 exact scan, 2 streaming scan, 3 f32 matrix cores, 4 bf16 prefilter + exact finish, 5 bf16 mirror")
     ap.add_argument("--mirror", action="store_true",
                     help="keep a bf16 copy of the corpus in HBM (1.5x memory): prefilter passes read half the bytes, "
@@ -92,8 +94,9 @@ def main():
     row0 = rank * per
     n_local = max(0, min(per, n_total - row0))
     seed = 1004
-    store = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, device=local, scan_mode=args.mode,
-                                                  reserve_rows=n_local))
+    metric_id = {"cosine": 0, "euclidean": 1, "dot": 2}[args.metric]
+    store = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, metric=pkg.DistanceMetric(metric_id), device=local,
+                                                  scan_mode=args.mode, reserve_rows=n_local))
     store.fill_synthetic(n_local, seed, first_global_row=row0)
     if args.mirror:
         store.set_bf16_mirror(True)
@@ -230,7 +233,7 @@ def main():
         mfma_peak = 2500.0 if bf16 else 157.3
         mfma_bound = mode_used in (3, 4) and b_launch / 2.0 >= mfma_peak * 1e12 / (HBM_PEAK_GBS * 1e9)
         result = {
-            "metric": "queries/sec, brute-force cosine top-10 over N x d fp32 (achieved HBM GB/s in roofline)",
+            "metric": f"queries/sec, brute-force {args.metric} top-10 over N x d fp32 (achieved HBM GB/s in roofline)",
             "value": args.steps * B / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
@@ -245,8 +248,8 @@ def main():
             "config": {"workload": (f"{n_total}x{d} fp32 corpus in HBM, hybrid step: dense cosine top-50 + BM25 "
                                     f"top-50 over {n_total} synthetic documents (both on the GPU) -> RRF(60) on "
                                     f"the host -> top-{args.k}") if args.hybrid else
-                       f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, cosine top-{k}",
-                       "rows": n_total, "dim": d, "k": k, "batch": B, "metric": "cosine",
+                       f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, {args.metric} top-{k}",
+                       "rows": n_total, "dim": d, "k": k, "batch": B, "metric": args.metric,
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
                        "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma", 4: "bf16-prefilter", 5: "bf16-mirror"}[args.mode],
                        "bf16_mirror": bool(args.mirror),
@@ -281,7 +284,7 @@ def main():
                                                     B, k, esz, sptr)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(store, Q, n_local, n_total, d, k, args.cpu_sample_rows,
-                                                  seed, row0)
+                                                  seed, row0, metric_id)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -353,7 +356,8 @@ def pmc_traffic(args):
     cmd = [exe, "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "-o", "p", "--",
            sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
            "--no-pmc", "--rows", str(args.rows), "--dim", str(args.dim), "--k", str(args.k),
-           "--mode", str(args.mode), "--batch", str(args.batch)] + (["--mirror"] if args.mirror else [])
+           "--mode", str(args.mode), "--batch", str(args.batch), "--metric", args.metric] + (
+               ["--mirror"] if args.mirror else [])
     env = dict(os.environ, TRAG_BENCH_CHILD="1", TMPDIR="/tmp")
     try:
         proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
@@ -395,7 +399,7 @@ def sparse_queries(n, vocab, n_terms, seed):
     return np.minimum(np.searchsorted(cdf, u, side="right"), vocab - 1).astype(np.uint32)
 
 
-def cpu_baseline(store, Q, n_local, n_total, d, k, sample_rows, seed, first_global_row):
+def cpu_baseline(store, Q, n_local, n_total, d, k, sample_rows, seed, first_global_row, metric_id=0):
     """The reference's CPU path (restated in oracle/, single thread as the
     reference is) timed on a bounded slice of the same corpus: about 10 s of CPU work."""
     from oracle import oracle
@@ -403,7 +407,7 @@ def cpu_baseline(store, Q, n_local, n_total, d, k, sample_rows, seed, first_glob
     sample = store.read_rows(0, m)
     n_q = 16
     qs = Q[-n_q:].cpu().numpy()
-    sec, _, _ = oracle.bench_faithful(sample, qs, k, oracle.COSINE)
+    sec, _, _ = oracle.bench_faithful(sample, qs, k, metric_id)
     per_query_full = sec * (n_total / m)
     # not the reference, for scale only: the same arithmetic over one contiguous N x d array
     # with the row loop spread over the host cores (OpenMP) and a partial selection instead of
@@ -411,17 +415,18 @@ def cpu_baseline(store, Q, n_local, n_total, d, k, sample_rows, seed, first_glob
     t = []
     for i in range(3):
         t0 = time.perf_counter()
-        oracle.search(sample, qs[i], k, oracle.COSINE)
+        oracle.search(sample, qs[i], k, metric_id)
         t.append(time.perf_counter() - t0)
     fast = sorted(t)[1] * (n_total / m)
     # parity against the oracle at the sample's size: a second store holding the same first m rows
     # (the generator is a pure function of (seed, row)), every mode the bench can use
     pkg = load_package()
-    sub = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, device=store.config().device, reserve_rows=m))
+    sub = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, metric=pkg.DistanceMetric(metric_id),
+                                                device=store.config().device, reserve_rows=m))
     sub.fill_synthetic(m, seed, first_global_row=first_global_row)
     same_rows, max_diff, ties = True, 0.0, 0
     for i in range(n_q):
-        er, es = oracle.search(sample, qs[i], k, oracle.COSINE)
+        er, es = oracle.search(sample, qs[i], k, metric_id)
         gr, gs = sub.search_rows(qs[i], k)
         same_rows = same_rows and np.array_equal(gr, er)
         max_diff = max(max_diff, float(np.max(np.abs(gs - es))) if len(es) else 0.0)

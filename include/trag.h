@@ -128,7 +128,12 @@ trag_status trag_store_search_batch(trag_store *s, const float *queries, uint32_
  * (1 ranking not certified, 2 candidate overflow, 3 crowded score bin needs the
  * multi-level select) means the fast path gave up and the caller must repeat
  * that query with trag_store_search / _batch, which handle all three
- * internally and remember the plan that worked for later calls. */
+ * internally and remember the plan that worked for later calls. The handle also
+ * learns from device-entry calls alone: the select kernel bumps a word in pinned
+ * host memory whenever a query reports 3, the next call reads it (no
+ * synchronisation), and once at least 4 queries and half of those enqueued so
+ * far reported 3 the multi-level select becomes the plan. A caller that enqueues
+ * hundreds of queries ahead of the GPU sees this take effect that much later. */
 trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint32_t n_queries,
                                      uint32_t dim, uint32_t k, uint32_t *d_out_rows,
                                      float *d_out_scores, uint32_t *d_out_n,

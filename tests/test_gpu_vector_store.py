@@ -751,3 +751,33 @@ def test_concurrent_searches_on_one_handle(trag, oracle):
     for t in threads:
         t.join()
     assert not errors, errors[0]
+
+
+def test_device_entry_learns_the_multi_level_select(trag, oracle):
+    """Callers of trag_store_search_device never hand a status back. On a corpus whose scores
+    crowd one coarse bin (Euclidean distances between unit vectors are all close to sqrt 2) the
+    first queries report status 3; the handle must notice by itself (pinned host word bumped by
+    the select kernel) and serve later queries with the multi-level select."""
+    import torch
+    n, d, k = 100_000, 384, 10
+    rng = np.random.default_rng(2718)
+    corpus = unit_rows(rng, n, d)
+    store = make_store(trag, d, 1)
+    store.insert_rows(corpus)
+    Q = unit_rows(rng, 24, d)
+    dq = torch.from_numpy(Q).cuda()
+    o_rows = torch.zeros((24, k), dtype=torch.int32, device="cuda")
+    o_scores = torch.zeros((24, k), dtype=torch.float32, device="cuda")
+    o_n = torch.zeros(24, dtype=torch.int32, device="cuda")
+    o_st = torch.full((24,), 9, dtype=torch.int32, device="cuda")
+    sp = torch.cuda.current_stream().cuda_stream
+    for b in range(24):
+        store.search_device(dq[b].data_ptr(), 1, k, o_rows[b].data_ptr(), o_scores[b].data_ptr(),
+                            o_n[b].data_ptr(), o_st[b].data_ptr(), sp)
+        torch.cuda.synchronize()
+    st = o_st.tolist()
+    assert st[0] == 3, st                 # crowded coarse bin
+    assert st[-8:] == [0] * 8, st         # learned within a few queries
+    for b in range(16, 24):
+        er, es = oracle.search(corpus, Q[b], k, 1)
+        assert_same_ranking(o_rows[b].cpu().numpy().astype(np.uint32), o_scores[b].cpu().numpy(), er, es, f"dev eu {b}")

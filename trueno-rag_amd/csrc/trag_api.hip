@@ -93,6 +93,8 @@ struct trag_store {
     uint32_t mirror_tries = 0, mirror_fails = 0;
     bool full_select = false;      // learned: this corpus needs the multi-level select
     uint32_t refine_calls = 0, select_calls = 0;  // calls that needed it / all calls, while it is not the plan
+    uint32_t* h_events = nullptr;  // host-pinned word the select kernels bump when a query needs it
+    uint64_t one_wg_queries = 0;   // queries enqueued with the one-workgroup select so far
     unsigned long long* d_sort = nullptr;  // large-k path: rank keys of every row, padded to 2^m
     unsigned long long sort_cap = 0;
     // staging for the host-pointer entry points
@@ -178,6 +180,13 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
 trag_status ensure_scratch(trag_store* s) {
     if (!s->scratch.cand) HIP_TRY(hipMalloc(&s->scratch.cand, CAND_CAP * sizeof(uint32_t)));
     if (!s->scratch.ckeys) HIP_TRY(hipMalloc(&s->scratch.ckeys, CAND_CAP * sizeof(uint32_t)));
+    if (!s->h_events) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_events), 64, hipHostMallocMapped));
+        *s->h_events = 0u;
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, s->h_events, 0));
+        s->scratch.events = static_cast<uint32_t*>(dp);
+    }
     if (s->keys_cap < s->cap_rows || !s->zero_block) {
         void* old[] = {s->scratch.keys, s->scratch.tmax, s->zero_block};
         for (void* p : old)
@@ -225,6 +234,7 @@ trag_status ensure_multi_scratch(trag_store* s) {
     HIP_TRY(hipMalloc(&s->mscratch.keys, ms.keys * MULTI_QUERIES * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->mscratch.tmax, ms.tmax * MULTI_QUERIES * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->mscratch.wmax, ms.wmax * MULTI_QUERIES * sizeof(uint32_t)));
+    s->mscratch.events = s->scratch.events;
     s->mscratch.ctl = reinterpret_cast<SearchCtl*>(s->m_zero_block);
     s->mscratch.hist = reinterpret_cast<uint32_t*>(static_cast<char*>(s->m_zero_block) + 256);
     s->mstride = ms;
@@ -370,6 +380,14 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     if (ts != TRAG_OK) return ts;
     const uint32_t live = (uint32_t)s->n_live;
     const uint32_t k_eff = std::min<uint32_t>(k, live);
+    // Callers of the device entry point never hand a status back, so the handle learns from the
+    // word the select kernels bump in pinned host memory (read as it is, no synchronisation):
+    // once at least 4 queries, and at least half of those enqueued so far, asked for the
+    // multi-level select, it becomes the plan.
+    if (!s->full_select && s->h_events) {
+        const uint32_t ev = *static_cast<volatile uint32_t*>(s->h_events);
+        if (ev >= 4 && (uint64_t)ev * 2 >= s->one_wg_queries) s->full_select = true;
+    }
     if (k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP) {
         // More results than the one-workgroup sort holds: exact scan, then a
         // global sort of every row's rank key (rare; the reference's callers ask
@@ -483,6 +501,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             HIP_TRY(launch_scan_mirror(s->d_mirror, q, s->d_norm2, a, s->scratch, need_m, k_eff, s->d_vmax_sq,
                                        &n_waves, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
+            if (!s->full_select) s->one_wg_queries += 1;
             HIP_TRY(launch_select_mirror(q, a, s->scratch, s->full_select, live, need_m, k_eff, n_waves,
                                          d_out_rows + (size_t)b * k, d_out_scores + (size_t)b * k, d_out_n + b,
                                          d_status ? d_status + b : nullptr, st));
@@ -529,6 +548,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             HIP_TRY(launch_scan_exact_multi(q, group, a, s->mscratch, s->mstride, need, k_eff, s->d_vmax_sq,
                                             &n_waves, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
+            s->one_wg_queries += group;
             HIP_TRY(launch_select_final(q, a, s->mscratch, false, live, need, k_eff, n_waves,
                                         d_out_rows + (size_t)b * k, d_out_scores + (size_t)b * k, d_out_n + b,
                                         d_status ? d_status + b : nullptr, st, group, &s->mstride, k));
@@ -545,6 +565,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         float* o_scores = d_out_scores + (size_t)b * k;
         uint32_t* o_status = d_status ? d_status + b : nullptr;
         if (!s->full_select) {
+            s->one_wg_queries += 1;
             HIP_TRY(launch_select_final(q, a, s->scratch, rescore, live, need, k_eff, n_waves, o_rows,
                                         o_scores, d_out_n + b, o_status, st));
         } else {
@@ -609,6 +630,7 @@ void trag_store_destroy(trag_store* s) {
                     s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->h_events) (void)hipHostFree(s->h_events);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }

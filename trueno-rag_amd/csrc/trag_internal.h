@@ -56,6 +56,8 @@ struct Scratch {
     uint32_t* ckeys;     // CAND_CAP exact ordered keys of the candidates (mirror scan, multi-level form)
     uint32_t* keys;      // capacity rows, ordered 32-bit keys (0 = removed row)
     uint32_t* tmax;      // capacity rows / 64: largest key of each 64-row tile
+    uint32_t* events;    // host-pinned, device-visible word (may be null): queries whose one-workgroup
+                         // select asked for the multi-level form; the host reads it without synchronising
 };
 
 // Device scratch of a block of queries on the batched (matrix-core) path.

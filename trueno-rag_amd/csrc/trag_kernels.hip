@@ -889,7 +889,8 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                     const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
                     const uint32_t* __restrict__ wmax, uint32_t* __restrict__ out_rows,
                     float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
-                    uint32_t* __restrict__ out_status, MultiStride ms, uint32_t out_stride) {
+                    uint32_t* __restrict__ out_status, MultiStride ms, uint32_t out_stride,
+                    uint32_t* __restrict__ events) {
     // one workgroup per query of a multi-query scan (blockIdx.x = query; strides 0 for one query)
     {
         const size_t b = blockIdx.x;
@@ -1049,6 +1050,8 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         ctl->levels = 1;
         ctl->status = status;
         if (out_status) *out_status = status;
+        if (status == ST_NEED_REFINE && events)
+            __hip_atomic_fetch_add(events, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1157,7 +1160,8 @@ __global__ void __launch_bounds__(1024)
 select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
                      SearchCtl* __restrict__ ctl, uint32_t* __restrict__ hist,
                      const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
-                     const uint32_t* __restrict__ wmax, uint32_t* __restrict__ cand) {
+                     const uint32_t* __restrict__ wmax, uint32_t* __restrict__ cand,
+                     uint32_t* __restrict__ events) {
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t hit[CAND_CAP];
     __shared__ uint32_t sh[24];
@@ -1311,6 +1315,8 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
         ctl->t_key = T_key;
         ctl->levels = 1;
         ctl->status = status;
+        if (status == ST_NEED_REFINE && events)
+            __hip_atomic_fetch_add(events, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1770,11 +1776,11 @@ static void select_final_dispatch(const float* d_q, const ScanArgs& a, const Scr
     if (rescore)
         hipLaunchKernelGGL((select_final_kernel<METRIC, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus,
                            d_q, a.n_rows, a.dim, live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax,
-                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride);
+                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride, s.events);
     else
         hipLaunchKernelGGL((select_final_kernel<METRIC, false>), dim3(n_queries), dim3(1024), 0, st, a.corpus,
                            d_q, a.n_rows, a.dim, live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax,
-                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride);
+                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride, s.events);
 }
 
 hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
@@ -1820,7 +1826,8 @@ hipError_t launch_select_mirror(const float* d_q, const ScanArgs& a, const Scrat
                                s.ctl, (const uint32_t*)nullptr, s.cand, (size_t)0, (size_t)0);             \
         } else {                                                                                           \
             hipLaunchKernelGGL(select_mirror_kernel<METRIC>, dim3(1), dim3(1024), 0, st, a.n_rows, a.dim,  \
-                               live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax, s.wmax, s.cand);     \
+                               live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax, s.wmax, s.cand,      \
+                               s.events);                                                                  \
         }                                                                                                  \
         hipLaunchKernelGGL(rescore_wave_kernel<METRIC>, dim3(256), dim3(256), 0, st, a.corpus, d_q,        \
                            a.n_rows, a.dim, s.ctl, s.cand, s.ckeys);                                       \
