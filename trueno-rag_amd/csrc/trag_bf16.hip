@@ -201,7 +201,8 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                 // All fragments of a k-step are read before its MFMAs start (scheduling barriers):
                 // left alone, the register allocator funnels the query fragments through one
                 // register and exposes a full LDS latency before every second MFMA (measured:
-                // matrix pipe 21 % busy).
+                // matrix pipe 21 % busy). Double-buffering the fragments in registers (reading those of
+                // step ks + 1 under the MFMAs of ks) measured slower: 256 queries x 1M x 768 0.75 -> 0.91 ms.
 #pragma unroll
                 for (int ks = 0; ks < BF_K / 16; ++ks) {
                     bf16x8 fa[TM], fb[2];
