@@ -182,11 +182,23 @@ def main():
     fence()
     # an event pair costs ~6 us of stream time: on sub-millisecond scans time every 4th launch only
     store.set_profiling(0 if os.environ.get("TRAG_BENCH_NO_PROFILE") else (4 if args.steps >= 40 else 1))
+    import gc
+    gc.collect()
+    gc.disable()   # as timeit does: a generation-2 collection of this process's heap is a ~70 ms pause
     t0 = time.perf_counter()
+    dbg = []
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+        if os.environ.get("TRAG_BENCH_DEBUG"):
+            dbg.append(time.perf_counter())
+    if dbg:
+        print("[debug] step ms:", [round(1e3 * (b - a), 2) for a, b in zip([t0] + dbg, dbg)], file=sys.stderr)
+    t_loop = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("TRAG_BENCH_DEBUG"):
+        print(f"[debug] loop {1e3 * t_loop:.2f} ms, fence {1e3 * (elapsed - t_loop):.2f} ms", file=sys.stderr)
     scan_ms, scan_launches = store.scan_time()
     store.set_profiling(False)
     mode_used = store.last_stats()["mode_used"]  # the path the timed steps actually took
