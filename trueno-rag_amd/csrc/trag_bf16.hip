@@ -104,6 +104,8 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     constexpr int NT = 64 * WGM * WGN;  // threads
     constexpr int PF = 1;               // steps of operand loads in flight (2 and 3 measured slower, also with the
                                         // mirror's small 32-register step: 256 queries x 1M x 768 0.634 -> 0.660 ms)
+    // (128-column staging steps, i.e. half the barriers, measured 5 % slower with the mirror and spill
+    // with f32 rows.)
     // (Two LDS stages with one barrier per k-step were measured too: 256 queries 3 % faster,
     // 32 queries 21 % slower -- one workgroup per CU where three fit with a single stage.)
     constexpr int BM = 32 * TM * WGM;   // queries per workgroup tile
