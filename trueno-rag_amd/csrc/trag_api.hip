@@ -371,6 +371,26 @@ uint32_t choose_mode(const trag_store* s, uint32_t n_queries, uint32_t k) {
     return pick_mode(s, s->cfg.scan_mode);
 }
 
+// Optional scan timing: every profile_every-th scan launch is bracketed by an event pair on
+// the stream it runs on. Records the opening event and hands back the closing one (nullptr
+// when this launch is not timed); the caller records it right after the scan launch.
+hipError_t scan_timer_begin(trag_store* s, hipStream_t st, hipEvent_t* closing) {
+    *closing = nullptr;
+    if (!s->profiling || s->ev_used >= 4096 || (s->profile_seen++ % s->profile_every) != 0) return hipSuccess;
+    if (s->ev_used == s->ev_pool.size()) {
+        hipEvent_t a0 = nullptr, a1 = nullptr;
+        hipError_t e = hipEventCreate(&a0);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&a1);
+        if (e != hipSuccess) { (void)hipEventDestroy(a0); return e; }
+        s->ev_pool.emplace_back(a0, a1);
+    }
+    const auto& pair = s->ev_pool[s->ev_used];
+    s->ev_used += 1;
+    *closing = pair.second;
+    return hipEventRecord(pair.first, st);
+}
+
 // Enqueue the pipeline for n_queries device-resident queries on `st`.
 // Caller holds s->mu, has set the device and made sure n_live > 0 and k > 0.
 trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_queries, uint32_t k,
@@ -421,19 +441,8 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         for (uint32_t b0 = 0; b0 < n_queries; b0 += BATCH_QUERIES) {
             const uint32_t nb = std::min<uint32_t>(BATCH_QUERIES, n_queries - b0);
             const float* Qb = d_queries + (size_t)b0 * s->cfg.dim;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
-                if (s->ev_used == s->ev_pool.size()) {
-                    hipEvent_t a0, a1;
-                    HIP_TRY(hipEventCreate(&a0));
-                    HIP_TRY(hipEventCreate(&a1));
-                    s->ev_pool.emplace_back(a0, a1);
-                }
-                e0 = s->ev_pool[s->ev_used].first;
-                e1 = s->ev_pool[s->ev_used].second;
-                s->ev_used += 1;
-                HIP_TRY(hipEventRecord(e0, st));
-            }
+            hipEvent_t e1 = nullptr;
+            HIP_TRY(scan_timer_begin(s, st, &e1));
             HIP_TRY(launch_bf16_scan(Qb, nb, a, s->d_mirror, s->d_norm2, s->bf16, k_eff, k_eff, s->d_vmax_sq, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
             HIP_TRY(launch_bf16_finish(Qb, nb, a, s->bf16, live, k, d_out_rows + (size_t)b0 * k,
@@ -452,19 +461,8 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         for (uint32_t b0 = 0; b0 < n_queries; b0 += BATCH_QUERIES) {
             const uint32_t nb = std::min<uint32_t>(BATCH_QUERIES, n_queries - b0);
             const float* Qb = d_queries + (size_t)b0 * s->cfg.dim;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
-                if (s->ev_used == s->ev_pool.size()) {
-                    hipEvent_t a0, a1;
-                    HIP_TRY(hipEventCreate(&a0));
-                    HIP_TRY(hipEventCreate(&a1));
-                    s->ev_pool.emplace_back(a0, a1);
-                }
-                e0 = s->ev_pool[s->ev_used].first;
-                e1 = s->ev_pool[s->ev_used].second;
-                s->ev_used += 1;
-                HIP_TRY(hipEventRecord(e0, st));
-            }
+            hipEvent_t e1 = nullptr;
+            HIP_TRY(scan_timer_begin(s, st, &e1));
             HIP_TRY(launch_batch_scan(Qb, nb, a, s->d_norm2, s->batch, need_b, k_eff, s->d_vmax_sq, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
             HIP_TRY(launch_batch_finish(Qb, nb, a, s->batch, live, k, d_out_rows + (size_t)b0 * k,
@@ -484,19 +482,8 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
         for (uint32_t b = 0; b < n_queries; ++b) {
             const float* q = d_queries + (size_t)b * s->cfg.dim;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
-                if (s->ev_used == s->ev_pool.size()) {
-                    hipEvent_t a0, a1;
-                    HIP_TRY(hipEventCreate(&a0));
-                    HIP_TRY(hipEventCreate(&a1));
-                    s->ev_pool.emplace_back(a0, a1);
-                }
-                e0 = s->ev_pool[s->ev_used].first;
-                e1 = s->ev_pool[s->ev_used].second;
-                s->ev_used += 1;
-                HIP_TRY(hipEventRecord(e0, st));
-            }
+            hipEvent_t e1 = nullptr;
+            HIP_TRY(scan_timer_begin(s, st, &e1));
             uint32_t n_waves = 0;
             HIP_TRY(launch_scan_mirror(s->d_mirror, q, s->d_norm2, a, s->scratch, need_m, k_eff, s->d_vmax_sq,
                                        &n_waves, st));
@@ -529,19 +516,8 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     }
     for (uint32_t b = 0; b < n_queries; ++b) {
         const float* q = d_queries + (size_t)b * s->cfg.dim;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (s->profiling && s->ev_used < 4096 && (s->profile_seen++ % s->profile_every) == 0) {
-            if (s->ev_used == s->ev_pool.size()) {
-                hipEvent_t a0, a1;
-                HIP_TRY(hipEventCreate(&a0));
-                HIP_TRY(hipEventCreate(&a1));
-                s->ev_pool.emplace_back(a0, a1);
-            }
-            e0 = s->ev_pool[s->ev_used].first;
-            e1 = s->ev_pool[s->ev_used].second;
-            s->ev_used += 1;
-            HIP_TRY(hipEventRecord(e0, st));
-        }
+        hipEvent_t e1 = nullptr;
+        HIP_TRY(scan_timer_begin(s, st, &e1));
         uint32_t n_waves = 0;
         const uint32_t group = multi_ok ? std::min<uint32_t>(multi_max, n_queries - b) : 1u;
         if (group >= 2) {
@@ -625,9 +601,12 @@ void trag_store_destroy(trag_store* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->d_mirror, s->batch.qpad, s->batch.ctls,
-                    s->batch.keys, s->batch.tmax, s->batch.cand, s->zero_block, s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys, s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax, s->d_sort, s->scratch.cand, s->scratch.ckeys, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->d_q, s->d_out_rows, s->d_out_scores,
-                    s->d_out_n, s->d_out_status};
+    void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->d_mirror,
+                    s->batch.qpad, s->batch.ctls, s->batch.keys, s->batch.tmax, s->batch.cand,
+                    s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys,
+                    s->zero_block, s->scratch.cand, s->scratch.ckeys, s->scratch.keys, s->scratch.tmax, s->scratch.wmax,
+                    s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax,
+                    s->d_sort, s->d_q, s->d_out_rows, s->d_out_scores, s->d_out_n, s->d_out_status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_events) (void)hipHostFree(s->h_events);
