@@ -683,8 +683,12 @@ rescore_kernel(const float* __restrict__ corpus, const float* __restrict__ Q, ui
 // Streaming / batched modes: every row left behind has an approximate score
 // <= t (the select threshold) and approximate and exact scores differ by at
 // most eps, so the exact top-k is final when its last member clears t + eps.
-// key_mode: 0 keys are approximate scores of the streaming / f32 matrix-core pass;
-// 2 keys of the f32 matrix-core Euclidean pass (negated squared distance);
+// key_mode: 0 keys are approximate scores of the streaming pass (IEEE fused multiply-adds,
+// any order: d * 2^-24 each for the approximate and the reference sum);
+// 1 keys of the f32 matrix-core pass: its products are exact but how the matrix pipe rounds
+// its running sums is not documented, so each of its d steps is given 2^-22 (as in the bf16
+// bound), 5d * 2^-24 with the reference's own d;
+// 2 keys of the f32 matrix-core Euclidean pass (negated squared distance), same steps;
 // 3 keys of the bf16 prefilter (Euclidean: negated squared distance);
 // 4 keys of the single-query scan of the bf16 mirror (score space for every metric).
 template <int METRIC>
@@ -692,7 +696,8 @@ __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float
                             float ek, int key_mode = 0) {
     uint32_t status = ST_OK;
     const float u = 5.9604645e-08f;  // 2^-24
-    float eps = (2.0f * (float)d + 64.0f) * u;
+    const float steps = (key_mode == 1 || key_mode == 2) ? 5.0f : 2.0f;
+    float eps = (steps * (float)d + 64.0f) * u;
     const float vmax = sqrtf(ctl->vmax_sq);
     // the bound assumes ||q||^2 is a normal number well inside the f32 range
     const float nsq = ctl->na_sq;
@@ -791,7 +796,7 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
         uint32_t status = ST_OK;
         if (RESCORE && C < live && n_out > 0)
             status = certify<METRIC>(ctl, d, na, ctl->t_key, key_score((uint32_t)(sk[n_out - 1] >> 32)),
-                                     use_count >= 2 ? use_count : 0);
+                                     use_count);  // 0 streaming, 1 / 2 f32 matrix cores, 3 bf16 prefilter
         if (overflow) status = ST_OVERFLOW;
         ctl->levels = ctl->resolved ? ctl->resolved : 3;
         ctl->status = status;
