@@ -64,7 +64,8 @@ __device__ __forceinline__ float bf16_unit_eps(uint32_t d) {
 template <int METRIC>
 __device__ __forceinline__ float mirror_eps(uint32_t d, float na, float vmax) {
     const float r = 0.00390625f * 1.003f;
-    const float f = (2.0f * (float)d + 64.0f) * 5.9604645e-08f * 1.01f;
+    // (cosine: 3d -- the two row norms are each off by d/2 * 2^-24 relative in either path)
+    const float f = ((METRIC == 0 ? 3.0f : 2.0f) * (float)d + 64.0f) * 5.9604645e-08f * 1.01f;
     if (METRIC == 0) return (r + f) * 1.01f + 1e-30f;
     if (METRIC == 2) return (r + f) * na * vmax * 1.01f + 1e-30f;
     return (r * vmax + f * (na + vmax)) * 1.01f + 1e-20f;

@@ -696,7 +696,8 @@ __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float
                             float ek, int key_mode = 0) {
     uint32_t status = ST_OK;
     const float u = 5.9604645e-08f;  // 2^-24
-    const float steps = (key_mode == 1 || key_mode == 2) ? 5.0f : 2.0f;
+    // (cosine: one more d for the two row norms, each off by d/2 * 2^-24 relative in either path)
+    const float steps = ((key_mode == 1 || key_mode == 2) ? 5.0f : 2.0f) + (METRIC == 0 ? 1.0f : 0.0f);
     float eps = (steps * (float)d + 64.0f) * u;
     const float vmax = sqrtf(ctl->vmax_sq);
     // the bound assumes ||q||^2 is a normal number well inside the f32 range
