@@ -294,7 +294,7 @@ def main():
         if world == 1 and not args.hybrid and not args.mirror and args.mode == 0:
             result["with_bf16_mirror"] = mirror_leg(store, args, Q, out_rows, out_scores, out_n, status, n_local, d,
                                                     B, k, esz, sptr)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg belongs to the single-GPU line only
             result["cpu_baseline"] = cpu_baseline(store, Q, n_local, n_total, d, k, args.cpu_sample_rows,
                                                   seed, row0, metric_id)
         print(json.dumps(result), flush=True)
