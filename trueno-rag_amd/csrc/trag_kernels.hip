@@ -1604,7 +1604,7 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
         // measured best on MI355X (10M x 384: 6.66 TB/s; 2 or 3 workgroups per CU 6.51 / 6.43,
         // one workgroup of 3 / 5 / 6 / 8 waves 6.35 / 6.51 / 6.50 / 6.47,
         // 64-float chunks 6.44 (with 2 / 3 waves per CU 5.93 / 6.26), default-policy instead of
-        // non-temporal loads 5.94).
+        // non-temporal loads 5.94; buffer loads with any of the sc0 / sc1 / nt policies at best 6.25 (nt)).
         static int n_cu = 0;
         if (n_cu == 0) {
             int dev = 0;
