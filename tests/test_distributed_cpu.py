@@ -90,3 +90,90 @@ def test_shard_ranges_cover_everything(trag):
             for r0, c in spans:
                 assert r0 == min(pos, n) or c == 0
                 pos += c
+
+
+class _OracleStore:
+    """Stand-in for a rank's VectorStore on machines without a GPU: same row-level methods,
+    answers from the CPU oracle."""
+
+    def __init__(self, oracle, d):
+        self.o, self.d = oracle, d
+        self.rows = np.zeros((0, d), dtype=np.float32)
+        self.dead = np.zeros(0, dtype=np.uint8)
+
+    def insert_rows(self, rows):
+        first = self.rows.shape[0]
+        self.rows = np.concatenate([self.rows, rows])
+        self.dead = np.concatenate([self.dead, np.zeros(rows.shape[0], np.uint8)])
+        return first
+
+    def remove_row(self, r):
+        self.dead[r] = 1
+
+    def len(self):
+        return int((self.dead == 0).sum())
+
+    def search_batch_rows(self, Q, k):
+        B = Q.shape[0]
+        rows = np.zeros((B, k), np.uint32)
+        scores = np.zeros((B, k), np.float32)
+        n = np.zeros(B, np.uint32)
+        for b in range(B):
+            if self.rows.shape[0]:
+                r, s = self.o.search(self.rows, Q[b], k, 0, dead=self.dead)
+                rows[b, :len(r)], scores[b, :len(s)], n[b] = r, s, len(r)
+        return rows, scores, n
+
+
+def _striped_worker(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import load_package
+    from oracle import oracle
+    load_package()
+    from trueno_rag_amd.sharded import ShardedVectorStore
+    d = 32
+    store = ShardedVectorStore(_OracleStore(oracle, d), max_queries=2)
+    corpus = oracle.synth_rows(99, 0, 1003, d)
+    corpus[500] = corpus[3]                                  # a tie across shards: lower global row first
+    assert store.insert_rows(corpus[:1]) == 0                # uneven blocks: stripes must stay in step
+    assert store.insert_rows(corpus[1:700]) == 1
+    assert store.insert_rows(corpus[700:]) == 700
+    for r in (3, 10, 11, 998):
+        store.remove_row(r)
+    n_live = store.len()
+    Q = np.concatenate([corpus[3:4], oracle.synth_rows(100, 0, 4, d)])
+    rows, scores, counts = store.search_batch_rows(Q, 20)
+    out_q.put((rank, n_live, rows, scores, counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_striped_store_matches_a_single_store(oracle):
+    world, d = 2, 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_striped_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    corpus = oracle.synth_rows(99, 0, 1003, d)
+    corpus[500] = corpus[3]
+    dead = np.zeros(1003, np.uint8)
+    dead[[3, 10, 11, 998]] = 1
+    Q = np.concatenate([corpus[3:4], oracle.synth_rows(100, 0, 4, d)])
+    for rank, n_live, rows, scores, counts in got:
+        assert n_live == 999
+        for b in range(5):
+            er, es = oracle.search(corpus, Q[b], 20, 0, dead=dead)
+            assert counts[b] == 20
+            assert rows[b].tolist() == er.tolist(), f"rank {rank} query {b}"
+            assert scores[b].tobytes() == es.tobytes()
+    assert got[0][2][0][0] == 500                            # row 3 removed: its duplicate, on the other shard, wins

@@ -781,3 +781,25 @@ def test_device_entry_learns_the_multi_level_select(trag, oracle):
     for b in range(16, 24):
         er, es = oracle.search(corpus, Q[b], k, 1)
         assert_same_ranking(o_rows[b].cpu().numpy().astype(np.uint32), o_scores[b].cpu().numpy(), er, es, f"dev eu {b}")
+
+
+def test_striped_store_on_one_gpu(trag, oracle):
+    """ShardedVectorStore with the real device store as its shard (world size 1: the exchange
+    degenerates to pack + merge on the GPU)."""
+    import torch
+    from trueno_rag_amd.sharded import ShardedVectorStore
+    n, d = 3000, 64
+    rng = np.random.default_rng(77)
+    corpus = unit_rows(rng, n, d)
+    st = ShardedVectorStore(make_store(trag, d), device=torch.device("cuda", torch.cuda.current_device()))
+    assert st.insert_rows(corpus[:1000]) == 0 and st.insert_rows(corpus[1000:]) == 1000
+    st.remove_row(42)
+    dead = np.zeros(n, np.uint8)
+    dead[42] = 1
+    Q = unit_rows(rng, 5, d)
+    rows, scores, counts = st.search_batch_rows(Q, 10)
+    assert st.len() == n - 1
+    for b in range(5):
+        er, es = oracle.search(corpus, Q[b], 10, 0, dead=dead)
+        assert counts[b] == 10
+        assert_same_ranking(rows[b], scores[b], er, es, f"striped {b}")

@@ -85,3 +85,86 @@ class ShardExchange:
                 out_rows.reshape(B, k)[b] = t.from_numpy(o_r.astype(np.int32))
                 out_scores.reshape(B, k)[b] = t.from_numpy(o_s)
                 out_counts.reshape(B)[b] = int(o_n.value)
+
+
+class ShardedVectorStore:
+    """A VectorStore striped over the ranks of a process group (one process per GPU).
+
+    Global row g lives on rank g % world as local row g // world: appends keep every shard
+    within one row of the others, global row ids never move, and ascending global row is
+    insertion order, so the tie rule of a single store (equal scores: lower row first) carries
+    over unchanged. Every rank calls every method with the same arguments (collective, like
+    torch.distributed itself); search returns the same merged result on every rank.
+
+    `local` is this rank's store: a trueno_rag_amd.VectorStore on its GPU, or any object with
+    insert_rows / search_batch_rows / remove_row / len (the CPU tests use an oracle-backed one).
+    No counterpart in the reference, which is single-process.
+    """
+
+    def __init__(self, local, k_max: int = 100, max_queries: int = 256, device=None, group=None):
+        import torch.distributed as dist
+        self.local = local
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_rows = 0                      # global rows ever inserted
+        self.k_max, self.max_queries, self.device = k_max, max_queries, device
+        self._ex = {}
+
+    def _exchange(self, k):
+        if k not in self._ex:
+            self._ex[k] = ShardExchange(k, max_queries=self.max_queries, device=self.device, group=self.group)
+        return self._ex[k]
+
+    def insert_rows(self, rows) -> int:
+        """Append an (n, dim) block (the same block on every rank); returns its first global row."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        g0 = self.n_rows
+        first = (self.rank - g0) % self.world          # index of this rank's first row in the block
+        mine = rows[first::self.world]
+        if mine.shape[0]:
+            local0 = self.local.insert_rows(mine)
+            assert local0 == (g0 + first) // self.world, "local store out of step with the striping"
+        self.n_rows += rows.shape[0]
+        return g0
+
+    def remove_row(self, global_row: int) -> None:
+        if global_row % self.world == self.rank:
+            self.local.remove_row(global_row // self.world)
+
+    def len(self) -> int:
+        import torch
+        import torch.distributed as dist
+        n = torch.tensor([int(self.local.len())], dtype=torch.int64,
+                         device=self.device if self.device is not None else "cpu")
+        if self.world > 1:
+            dist.all_reduce(n, group=self.group)
+        return int(n.item())
+
+    def search_batch_rows(self, queries, k: int):
+        """(global rows [B, k], scores [B, k], counts [B]) of the merged top k, on every rank."""
+        import torch
+        Q = np.ascontiguousarray(queries, dtype=np.float32)
+        B = Q.shape[0]
+        if k == 0 or B == 0:
+            return (np.zeros((B, 0), np.uint32), np.zeros((B, 0), np.float32), np.zeros(B, np.uint32))
+        rows, scores, counts = self.local.search_batch_rows(Q, k)
+        dev = self.device if self.device is not None else torch.device("cpu")
+        g = rows.astype(np.int64) * self.world + self.rank            # local row -> global row
+        lr = torch.from_numpy(g.astype(np.int32)).to(dev)
+        ls = torch.from_numpy(np.ascontiguousarray(scores, dtype=np.float32)).to(dev)
+        ln = torch.from_numpy(counts.astype(np.int32)).to(dev)
+        o_r = torch.zeros((B, k), dtype=torch.int32, device=dev)
+        o_s = torch.zeros((B, k), dtype=torch.float32, device=dev)
+        o_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        ex = self._exchange(k)
+        for b0 in range(0, B, self.max_queries):
+            b1 = min(B, b0 + self.max_queries)
+            ex.exchange(lr[b0:b1], ls[b0:b1], ln[b0:b1], 0, o_r[b0:b1], o_s[b0:b1], o_n[b0:b1])
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        return (o_r.cpu().numpy().astype(np.uint32), o_s.cpu().numpy(), o_n.cpu().numpy().astype(np.uint32))
+
+    def search_rows(self, query, k: int):
+        r, s, n = self.search_batch_rows(np.asarray(query, dtype=np.float32)[None, :], k)
+        return r[0, :n[0]], s[0, :n[0]]
