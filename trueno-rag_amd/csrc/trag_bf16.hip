@@ -22,6 +22,7 @@
 // corpus (converted to bf16 on the way into LDS) up to several hundred queries.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "trag_device.h"
 #include "trag_internal.h"
@@ -93,7 +94,13 @@ __global__ void shift_threshold_kernel(SearchCtl* __restrict__ ctls, uint32_t n_
 // MIR: the corpus operand comes from the bf16 mirror (half the bytes, no conversion);
 // the mirror holds exactly the values the conversion below produces, so both forms of
 // the pass compute the same accumulators.
-template <int METRIC, int TM, int WGM, int WGN, int MODE, bool MIR>
+// DMA (needs MIR): both operands are bf16 in memory, so nothing has to pass through registers on its
+// way to LDS: `global_load_lds_dwordx4` moves 16 bytes per lane straight into LDS (a wave-instruction
+// fills 1 KB = 8 rows x 128 bytes), two stages alternate, and a k-step costs ONE barrier: wait for
+// this step's data, barrier, start the next step's transfers into the other stage, multiply. The LDS
+// rows are unpadded (128 bytes); bank conflicts are avoided by storing 16-byte chunk c of row r at
+// slot c ^ ((r >> 1) & 7) -- the permutation is applied to the global address each lane fetches.
+template <int METRIC, int TM, int WGM, int WGN, int MODE, bool MIR, bool DMA = false>
 __global__ void __launch_bounds__(64 * WGM * WGN)
 gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mirror,
                  const __bf16* __restrict__ Qb,
@@ -112,8 +119,12 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     constexpr int BN = 64 * WGN;        // corpus rows per workgroup tile
     constexpr int NLA = BM * 8 / NT;    // 16-byte chunks of the query tile per thread and step
     constexpr int NLB = MIR ? BN * 8 / NT : BN * 16 / NT;  // 16-byte chunks (8 bf16 / 4 f32) of the corpus tile per thread and step
-    __shared__ __attribute__((aligned(16))) uint32_t As[BM * BF_LD];
-    __shared__ __attribute__((aligned(16))) uint32_t Bs[BN * BF_LD];
+    static_assert(!DMA || MIR, "direct-to-LDS staging needs bf16 operands in memory");
+    constexpr int LDS_DWORDS = DMA ? (BM + BN) * 32 : (BM + BN) * BF_LD;
+    __shared__ __attribute__((aligned(1024))) uint32_t lds0[LDS_DWORDS];            // (DMA: stage 0)
+    __shared__ __attribute__((aligned(1024))) uint32_t lds1[DMA ? LDS_DWORDS : 4];  // DMA: stage 1
+    uint32_t* const As = lds0;
+    uint32_t* const Bs = lds0 + BM * (DMA ? 32 : BF_LD);
     __shared__ __attribute__((aligned(16))) float qs_s[BM];  // MODE 1: the queries' thresholds
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
@@ -131,6 +142,95 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     if (MODE == 1 && tid < BM) qs_s[tid] = (q0 + tid < n_queries) ? thr[q0 + tid] : INFINITY;
 
     const uint32_t nk = d / BF_K;
+    v16f acc[TM][2];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    const int frow = lane & 31, half = lane >> 5;
+
+    if constexpr (DMA) {
+        constexpr int NW = NT / 64;           // waves
+        constexpr int NA = BM / 8 / NW;       // 8-row blocks of the query tile per wave and step
+        constexpr int NB = BN / 8 / NW;       // ... of the corpus tile
+        const int lrow = lane >> 3, slot = lane & 7;
+        const __bf16* asrc[NA];
+        const uint16_t* bsrc[NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = (wid * NA + i) * 8 + lrow;
+            asrc[i] = Qb + (size_t)(q0 + row) * d + ((slot ^ ((row >> 1) & 7)) << 3);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = (wid * NB + i) * 8 + lrow;
+            const uint32_t r = min(n0 + (uint32_t)row, n_rows - 1u);
+            bsrc[i] = mirror + (size_t)r * d + ((slot ^ ((row >> 1) & 7)) << 3);
+        }
+        typedef __attribute__((address_space(3))) void* lds_ptr;
+        typedef const __attribute__((address_space(1))) void* glb_ptr;
+        auto transfer = [&](uint32_t* dst, uint32_t kt) __attribute__((always_inline)) {
+            uint32_t* b_dst = dst + BM * 32;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[i] + (size_t)kt * BF_K),
+                                                 (lds_ptr)(dst + (wid * NA + i) * 256), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_global_load_lds((glb_ptr)(bsrc[i] + (size_t)kt * BF_K),
+                                                 (lds_ptr)(b_dst + (wid * NB + i) * 256), 16, 0, 2 /* nt */);
+        };
+        const int sw = (frow >> 1) & 7;
+        // One k-step: start the next step's transfers into `nxt`, multiply out of `cur`. The two
+        // stages reach this helper as distinct __restrict__ arguments: the alias scopes that gives
+        // the accesses let the compiler see that the fragment reads do not depend on the transfers
+        // just issued (otherwise it waits for them before the first read and nothing overlaps).
+        auto kstep = [&](const uint32_t* __restrict__ cur, uint32_t* __restrict__ nxt, bool more, uint32_t kt_next)
+                         __attribute__((always_inline)) {
+            if (more) transfer(nxt, kt_next);
+            const uint32_t* Bc = cur + BM * 32;
+            // fragments ping-pong through two register sets: those of MFMA step ks + 1 are read
+            // while the MFMAs of step ks run (the staging registers this path does not need pay for it)
+            bf16x8 fa[2][TM], fb[2][2];
+            auto frags = [&](int buf, int ks) {
+                const int chunk = ((ks * 2 + half) ^ sw) << 2;
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+                    fa[buf][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                        &cur[(wm * 32 * TM + m * 32 + frow) * 32 + chunk]));
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    fb[buf][n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                        &Bc[(wn * 64 + n * 32 + frow) * 32 + chunk]));
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < BF_K / 16; ++ks) {
+                if (ks + 1 < BF_K / 16) frags((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        transfer(lds0, 0u);
+        for (uint32_t kt = 0; kt < nk; kt += 2) {
+            __syncthreads();  // this step's transfers have landed (every wave waited for its own before
+                              // the barrier) and every wave is done with the other stage
+            kstep(lds0, lds1, kt + 1u < nk, kt + 1u);
+            if (kt + 1u < nk) {
+                __syncthreads();
+                kstep(lds1, lds0, kt + 2u < nk, kt + 2u);
+            }
+        }
+        // (A persistent form -- one workgroup per CU walking through its tiles, step 0 of the next
+        // tile in flight during the epilogue -- measured 6 % slower: the extra live pointers spill.)
+    } else {
     const u32x4* aptr[NLA];
     const char* bptr[NLB];
     int a_off[NLA], b_off[NLB];
@@ -181,15 +281,6 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     for (int s = 0; s < PF; ++s)
         if ((uint32_t)s < nk) prefetch(s, (uint32_t)s);
 
-    v16f acc[TM][2];
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-    const int frow = lane & 31, half = lane >> 5;
     for (uint32_t kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
@@ -226,6 +317,8 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                 }
             }
         }
+    }
+
     }
 
     // ---- epilogue. v = the row-dependent part of the score, per accumulator:
@@ -370,7 +463,12 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
     if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
     else if (variant == 1) TRAG_LAUNCH_BF16(2, 1, 4);  // 64 x 256
     else if (variant == 2) TRAG_LAUNCH_BF16(2, 2, 2);  // 128 x 128
-    else TRAG_LAUNCH_BF16(4, 2, 4);                    // 256 x 256, eight waves (two per SIMD)
+    else if (MIR && !getenv("TRAG_BF16_NODMA")) {      // 256 x 256 from the mirror: direct-to-LDS staging
+        if constexpr (MIR)
+            hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, 4, 2, 4, MODE, true, true>), dim3(grid), dim3(512), 0, st,
+                               a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows,
+                               a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand);
+    } else TRAG_LAUNCH_BF16(4, 2, 4);                  // 256 x 256, eight waves (two per SIMD)
 #undef TRAG_LAUNCH_BF16
 }
 
