@@ -401,7 +401,7 @@ scan_exact_any_kernel(const float* __restrict__ corpus, const float* __restrict_
 // reaches `need`, and the count strictly above it. sh: NT/64 + 2 words of LDS.
 template <int NT>
 __device__ void find_bin(const uint32_t* __restrict__ hist, uint32_t need, uint32_t& bin,
-                         uint32_t& above, uint32_t* sh) {
+                         uint32_t& above, uint32_t* sh, uint32_t* in_bin = nullptr) {
     constexpr int BPT = (int)HIST_BINS / NT;  // bins per thread
     constexpr int NW = NT / 64;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -416,7 +416,7 @@ __device__ void find_bin(const uint32_t* __restrict__ hist, uint32_t need, uint3
         if (lane >= o) incl += v;
     }
     if (lane == 63) sh[w] = incl;
-    if (t == 0) { sh[NW] = 0; sh[NW + 1] = 0; }
+    if (t == 0) { sh[NW] = 0; sh[NW + 1] = 0; sh[NW + 2] = hist[0]; }
     __syncthreads();
     uint32_t base = 0, total = 0;
     for (int i = 0; i < NW; ++i) {
@@ -430,13 +430,14 @@ __device__ void find_bin(const uint32_t* __restrict__ hist, uint32_t need, uint3
         uint32_t cum = excl;
 #pragma unroll
         for (int i = 0; i < BPT; ++i) {
-            if (cum + h[i] >= need) { sh[NW] = (uint32_t)(top - i); sh[NW + 1] = cum; break; }
+            if (cum + h[i] >= need) { sh[NW] = (uint32_t)(top - i); sh[NW + 1] = cum; sh[NW + 2] = h[i]; break; }
             cum += h[i];
         }
     }
     __syncthreads();
     bin = sh[NW];
     above = sh[NW + 1];
+    if (in_bin) *in_bin = sh[NW + 2];  // rows in that bin (saves the caller a dependent global load)
     __syncthreads();
 }
 
@@ -922,8 +923,9 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     float na = 0.0f;
     if (RESCORE) na = ctl->na;
     uint32_t b1, above1;
-    find_bin<1024>(hist, need, b1, above1, sh);
-    const uint32_t expect = above1 + hist[b1];
+    uint32_t inbin1;
+    find_bin<1024>(hist, need, b1, above1, sh, &inbin1);
+    const uint32_t expect = above1 + inbin1;
     uint32_t status = ST_OK, n_out = 0, C = 0;
     if (expect > CAND_CAP) {
         status = ST_NEED_REFINE;
@@ -1175,10 +1177,11 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     const uint32_t my_wmax = ((uint32_t)tid < n_waves && (uint32_t)tid < n_tiles) ? wmax[tid] : 0u;
-    const float na = ctl->na;
-    uint32_t b1, above1;
-    find_bin<1024>(hist, need, b1, above1, sh);
-    const uint32_t expect = above1 + hist[b1];
+    // (the control block's fields are fetched up front: their latency hides behind the histogram scan)
+    const float na = ctl->na, nsq = ctl->na_sq, vmax = sqrtf(ctl->vmax_sq);
+    uint32_t b1, above1, inbin1;
+    find_bin<1024>(hist, need, b1, above1, sh, &inbin1);
+    const uint32_t expect = above1 + inbin1;
     if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; n_thit_sh = 0; extra_sh = 0; nf_sh = 0; ns_sh = 0; akey_sh = 0; }
     __syncthreads();
     // append the rows with lo <= key < hi to sk[] (through the wave maxima, then the tile
@@ -1265,9 +1268,7 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
             }
             __syncthreads();
         }
-        const float vmax = sqrtf(ctl->vmax_sq);
         const float eps = mirror_eps<METRIC>(d, na, vmax);
-        const float nsq = ctl->na_sq;
         if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f)) || !(eps < INFINITY)) status = ST_UNCERTIFIED;
         if (akey_sh >= 0x007FFFFFu) {
             const float T = key_score(akey_sh) - 2.02f * eps;
