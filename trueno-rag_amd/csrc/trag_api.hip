@@ -100,11 +100,18 @@ struct trag_store {
     // staging for the host-pointer entry points
     float* d_q = nullptr;
     uint64_t d_q_cap = 0;          // floats
-    uint32_t* d_out_rows = nullptr;
+    // results of a host-pointer call live in ONE device block, laid out per call as
+    //   rows [nq * k] | scores [nq * k] | counts [nq] | statuses [nq] | control block of the last query,
+    // so that one copy into pinned host memory brings everything back
+    uint32_t* d_out_block = nullptr;
+    uint32_t* h_out_block = nullptr;  // pinned
+    uint64_t out_cap_words = 0;
+    float* h_q = nullptr;             // pinned staging of the queries
+    uint64_t h_q_cap = 0;             // floats
+    uint32_t* d_out_rows = nullptr;   // the four views of the current call
     float* d_out_scores = nullptr;
     uint32_t* d_out_n = nullptr;
     uint32_t* d_out_status = nullptr;
-    uint64_t out_cap_q = 0, out_cap_k = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
     trag_search_stats stats{};
@@ -242,7 +249,10 @@ trag_status ensure_multi_scratch(trag_store* s) {
     return TRAG_OK;
 }
 
+constexpr uint64_t OUT_CTL_WORDS = 64;  // room for a SearchCtl behind the results (diagnostics)
+
 trag_status ensure_staging(trag_store* s, uint64_t nq, uint64_t k) {
+    static_assert(sizeof(SearchCtl) <= OUT_CTL_WORDS * sizeof(uint32_t), "control block grew");
     const uint64_t need_q = nq * s->cfg.dim;
     if (need_q > s->d_q_cap) {
         if (s->d_q) (void)hipFree(s->d_q);
@@ -251,21 +261,30 @@ trag_status ensure_staging(trag_store* s, uint64_t nq, uint64_t k) {
         HIP_TRY(hipMalloc(&s->d_q, need_q * sizeof(float)));
         s->d_q_cap = need_q;
     }
-    if (nq > s->out_cap_q || k > s->out_cap_k) {
-        const uint64_t cq = std::max(nq, s->out_cap_q), ck = std::max<uint64_t>(std::max(k, s->out_cap_k), 1);
-        if (s->d_out_rows) (void)hipFree(s->d_out_rows);
-        if (s->d_out_scores) (void)hipFree(s->d_out_scores);
-        if (s->d_out_n) (void)hipFree(s->d_out_n);
-        if (s->d_out_status) (void)hipFree(s->d_out_status);
-        s->d_out_rows = nullptr; s->d_out_scores = nullptr; s->d_out_n = nullptr; s->d_out_status = nullptr;
-        s->out_cap_q = s->out_cap_k = 0;
-        HIP_TRY(hipMalloc(&s->d_out_rows, cq * ck * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&s->d_out_scores, cq * ck * sizeof(float)));
-        HIP_TRY(hipMalloc(&s->d_out_n, cq * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&s->d_out_status, cq * sizeof(uint32_t)));
-        s->out_cap_q = cq;
-        s->out_cap_k = ck;
+    if (need_q > s->h_q_cap) {
+        if (s->h_q) (void)hipHostFree(s->h_q);
+        s->h_q = nullptr;
+        s->h_q_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_q), need_q * sizeof(float), hipHostMallocDefault));
+        s->h_q_cap = need_q;
     }
+    const uint64_t kk = std::max<uint64_t>(k, 1);
+    const uint64_t words = 2 * nq * kk + 2 * nq + OUT_CTL_WORDS;
+    if (words > s->out_cap_words) {
+        if (s->d_out_block) (void)hipFree(s->d_out_block);
+        if (s->h_out_block) (void)hipHostFree(s->h_out_block);
+        s->d_out_block = nullptr;
+        s->h_out_block = nullptr;
+        s->out_cap_words = 0;
+        const uint64_t cap = std::max<uint64_t>(words, 4096);
+        HIP_TRY(hipMalloc(&s->d_out_block, cap * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_out_block), cap * sizeof(uint32_t), hipHostMallocDefault));
+        s->out_cap_words = cap;
+    }
+    s->d_out_rows = s->d_out_block;
+    s->d_out_scores = reinterpret_cast<float*>(s->d_out_block + nq * kk);
+    s->d_out_n = s->d_out_block + 2 * nq * kk;
+    s->d_out_status = s->d_out_n + nq;
     return TRAG_OK;
 }
 
@@ -606,10 +625,12 @@ void trag_store_destroy(trag_store* s) {
                     s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys,
                     s->zero_block, s->scratch.cand, s->scratch.ckeys, s->scratch.keys, s->scratch.tmax, s->scratch.wmax,
                     s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax,
-                    s->d_sort, s->d_q, s->d_out_rows, s->d_out_scores, s->d_out_n, s->d_out_status};
+                    s->d_sort, s->d_q, s->d_out_block};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_events) (void)hipHostFree(s->h_events);
+    if (s->h_q) (void)hipHostFree(s->h_q);
+    if (s->h_out_block) (void)hipHostFree(s->h_out_block);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -763,22 +784,36 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
     trag_status ts = ensure_staging(s, n_queries, k);
     if (ts != TRAG_OK) return ts;
     hipStream_t st = s->stream;
-    HIP_TRY(hipMemcpyAsync(s->d_q, queries, (size_t)n_queries * dim * sizeof(float),
-                           hipMemcpyHostToDevice, st));
+    // queries go up through pinned memory (a truly asynchronous copy), everything comes back in
+    // ONE copy of the result block into pinned memory: rows, scores, counts, statuses and the
+    // control block the diagnostics read (five pageable copies cost ~60 us per call)
+    std::memcpy(s->h_q, queries, (size_t)n_queries * dim * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(s->d_q, s->h_q, (size_t)n_queries * dim * sizeof(float), hipMemcpyHostToDevice, st));
     uint32_t mode = choose_mode(s, n_queries, k);
     ts = enqueue_search(s, s->d_q, n_queries, k, mode, s->d_out_rows, s->d_out_scores, s->d_out_n,
                         s->d_out_status, st);
     if (ts != TRAG_OK) return ts;
     std::vector<uint32_t> status(n_queries);
-    HIP_TRY(hipMemcpyAsync(out_rows, s->d_out_rows, (size_t)n_queries * k * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_scores, s->d_out_scores, (size_t)n_queries * k * sizeof(float),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_n, s->d_out_n, (size_t)n_queries * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(status.data(), s->d_out_status, (size_t)n_queries * sizeof(uint32_t),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    SearchCtl ctl{};
+    const size_t nk_words = (size_t)n_queries * k, res_words = 2 * nk_words + 2 * (size_t)n_queries;
+    auto fetch = [&](uint32_t m) -> trag_status {
+        const void* ctl_src = m == TRAG_SCAN_BF16 ? (const void*)s->bf16.ctls
+                              : m == TRAG_SCAN_MFMA ? (const void*)s->batch.ctls
+                              : (const void*)(s->last_ctl ? s->last_ctl : s->scratch.ctl);
+        HIP_TRY(hipMemcpyAsync(s->d_out_block + res_words, ctl_src, sizeof(SearchCtl), hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->h_out_block, s->d_out_block, (res_words + OUT_CTL_WORDS) * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint32_t* h = s->h_out_block;
+        std::memcpy(out_rows, h, nk_words * sizeof(uint32_t));
+        std::memcpy(out_scores, h + nk_words, nk_words * sizeof(float));
+        std::memcpy(out_n, h + 2 * nk_words, n_queries * sizeof(uint32_t));
+        std::memcpy(status.data(), h + 2 * nk_words + n_queries, n_queries * sizeof(uint32_t));
+        std::memcpy(&ctl, h + res_words, sizeof(SearchCtl));
+        return TRAG_OK;
+    };
+    ts = fetch(mode);
+    if (ts != TRAG_OK) return ts;
     s->stats.fallbacks = 0;
     // A corpus whose scores cluster (many rows within the bf16 bound of the k-th best)
     // overflows the prefilter's lists for many queries at once: repeat the whole batch on
@@ -793,15 +828,8 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
             ts = enqueue_search(s, s->d_q, n_queries, k, mode, s->d_out_rows, s->d_out_scores, s->d_out_n,
                                 s->d_out_status, st);
             if (ts != TRAG_OK) return ts;
-            HIP_TRY(hipMemcpyAsync(out_rows, s->d_out_rows, (size_t)n_queries * k * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_scores, s->d_out_scores, (size_t)n_queries * k * sizeof(float),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_n, s->d_out_n, (size_t)n_queries * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(status.data(), s->d_out_status, (size_t)n_queries * sizeof(uint32_t),
-                                   hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            ts = fetch(mode);
+            if (ts != TRAG_OK) return ts;
         }
     }
     // Repeat what the fast paths could not finish. A crowded coarse bin
@@ -809,7 +837,7 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
     // for later queries on this handle; an uncertified or overflowing
     // streaming / matrix-core result is repeated with the exact scan.
     const bool was_full = s->full_select;
-    bool any_refine = false;
+    bool any_refine = false, retried = false;
     for (uint32_t b = 0; b < n_queries; ++b) {
         uint32_t cur_mode = mode;
         for (int attempt = 0; attempt < 3 && status[b] != ST_OK; ++attempt) {
@@ -826,13 +854,9 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
                                 s->d_out_rows + (size_t)b * k, s->d_out_scores + (size_t)b * k,
                                 s->d_out_n + b, s->d_out_status + b, st);
             if (ts != TRAG_OK) return ts;
-            HIP_TRY(hipMemcpyAsync(out_rows + (size_t)b * k, s->d_out_rows + (size_t)b * k,
-                                   k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_scores + (size_t)b * k, s->d_out_scores + (size_t)b * k,
-                                   k * sizeof(float), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_n + b, s->d_out_n + b, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&status[b], s->d_out_status + b, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            ts = fetch(cur_mode);  // (rare path: the whole block again, this query's slots now final)
+            if (ts != TRAG_OK) return ts;
+            retried = true;
         }
         if (status[b] != ST_OK)
             return fail(TRAG_DEVICE_ERROR, "search could not be completed (status " +
@@ -855,15 +879,14 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
             s->mirror_off = true;
     }
     s->stats.mode_used = mode;
-    if (mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16) {
-        SearchCtl ctl;
-        HIP_TRY(hipMemcpy(&ctl, mode == TRAG_SCAN_BF16 ? s->bf16.ctls : s->batch.ctls, sizeof(ctl),
-                          hipMemcpyDeviceToHost));
+    if (retried && (mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16)) {
+        ts = fetch(mode);  // the diagnostics describe the batch's own pass, not a repeated query's
+        if (ts != TRAG_OK) return ts;
+    }
+    if (mode == TRAG_SCAN_MFMA || mode == TRAG_SCAN_BF16) {   // (ctl: the copy that came back with the results)
         s->stats.candidates = ctl.cand_count;
         s->stats.refine_levels = 0;
     } else {
-        SearchCtl ctl;
-        HIP_TRY(hipMemcpy(&ctl, s->last_ctl ? s->last_ctl : s->scratch.ctl, sizeof(ctl), hipMemcpyDeviceToHost));
         s->stats.candidates = ctl.expect;
         s->stats.refine_levels = ctl.levels;
     }

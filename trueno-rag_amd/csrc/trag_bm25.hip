@@ -156,7 +156,8 @@ struct trag_bm25 {
     Scratch scratch{};
     void* zero_block = nullptr;
     size_t zero_bytes = 0;
-    uint32_t* d_out = nullptr;          // staging: k docs | k scores | n | status
+    uint32_t* d_out = nullptr;          // staging, laid out per call: k docs | k scores | n | status
+    uint32_t* h_out = nullptr;          // its pinned host copy (one transfer per search)
     uint32_t out_cap_k = 0;
 };
 
@@ -173,6 +174,8 @@ void free_device(trag_bm25* ix) {
     ix->scratch = Scratch{};
     ix->zero_block = nullptr;
     ix->d_out = nullptr;
+    if (ix->h_out) (void)hipHostFree(ix->h_out);
+    ix->h_out = nullptr;
     ix->post_cap = ix->doc_cap = 0;
     ix->out_cap_k = 0;
 }
@@ -244,12 +247,16 @@ trag_status commit(trag_bm25* ix) {
 }
 
 trag_status ensure_out(trag_bm25* ix, uint32_t k) {
-    if (k <= ix->out_cap_k && ix->d_out) return TRAG_OK;
+    if (k <= ix->out_cap_k && ix->d_out && ix->h_out) return TRAG_OK;
     if (ix->d_out) (void)hipFree(ix->d_out);
+    if (ix->h_out) (void)hipHostFree(ix->h_out);
     ix->d_out = nullptr;
+    ix->h_out = nullptr;
     ix->out_cap_k = 0;
     const uint32_t cap = std::max<uint32_t>(k, 64);
     BM_TRY(hipMalloc(&ix->d_out, ((size_t)2 * cap + 2) * sizeof(uint32_t)));
+    BM_TRY(hipHostMalloc(reinterpret_cast<void**>(&ix->h_out), ((size_t)2 * cap + 2) * sizeof(uint32_t),
+                         hipHostMallocDefault));
     ix->out_cap_k = cap;
     return TRAG_OK;
 }
@@ -455,14 +462,15 @@ trag_status trag_bm25_search(trag_bm25* ix, const uint32_t* query_terms, uint32_
     if (ts != TRAG_OK) return ts;
     hipStream_t st = ix->stream;
     uint32_t* d_docs = ix->d_out;
-    float* d_scores = reinterpret_cast<float*>(ix->d_out + ix->out_cap_k);
-    uint32_t* d_n = ix->d_out + 2 * (size_t)ix->out_cap_k;
+    float* d_scores = reinterpret_cast<float*>(ix->d_out + k);
+    uint32_t* d_n = ix->d_out + 2 * (size_t)k;
     uint32_t* d_status = d_n + 1;
-    uint32_t tail[2] = {0, 0};
+    const uint32_t* tail = ix->h_out + 2 * (size_t)k;  // {count, status} once the block is back
     for (int attempt = 0; attempt < 2; ++attempt) {
         ts = enqueue_query(ix, query_terms, n_terms, k, d_docs, d_scores, d_n, d_status, st);
         if (ts != TRAG_OK) return ts;
-        BM_TRY(hipMemcpyAsync(tail, d_n, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        // one transfer into pinned memory brings documents, scores, count and status back
+        BM_TRY(hipMemcpyAsync(ix->h_out, ix->d_out, ((size_t)2 * k + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         BM_TRY(hipStreamSynchronize(st));
         if (tail[1] != ST_NEED_REFINE) break;
         ix->full_select = true;  // crowded coarse bin: use the multi-level select from now on
@@ -471,9 +479,8 @@ trag_status trag_bm25_search(trag_bm25* ix, const uint32_t* query_terms, uint32_
         return set_error(TRAG_DEVICE_ERROR, "search could not be completed (status " + std::to_string(tail[1]) + ")");
     const uint32_t n = std::min(tail[0], k);
     if (n) {
-        BM_TRY(hipMemcpyAsync(out_docs, d_docs, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        BM_TRY(hipMemcpyAsync(out_scores, d_scores, n * sizeof(float), hipMemcpyDeviceToHost, st));
-        BM_TRY(hipStreamSynchronize(st));
+        std::memcpy(out_docs, ix->h_out, n * sizeof(uint32_t));
+        std::memcpy(out_scores, ix->h_out + k, n * sizeof(float));
     }
     *out_n = n;
     return TRAG_OK;
