@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--sparse-terms", type=int, default=8)
     ap.add_argument("--hybrid", action="store_true",
                     help="hybrid step: dense top-50 + BM25 top-50 (synthetic documents) -> RRF(60) -> top-k on the host")
+    ap.add_argument("--host", action="store_true",
+                    help="time the host-pointer entry (trag_store_search: query from host memory, results to host "
+                         "memory, synchronous) instead of the device-resident one; the shape of BASELINE config 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter pass that measures the scan kernel's HBM traffic")
@@ -79,7 +82,7 @@ def main():
     # in this process, and a GPU-initialised process must not start other programs)
     profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
         n.startswith(("ROCPROF", "ROCP_")) for n in os.environ)
-    if (world == 1 and not args.no_pmc and not args.hybrid and not profiled
+    if (world == 1 and not args.no_pmc and not args.hybrid and not args.host and not profiled
             and not os.environ.get("TRAG_BENCH_CHILD")):
         traffic = pmc_traffic(args)
     torch.cuda.set_device(local)
@@ -156,10 +159,16 @@ def main():
         sparse = list(zip(s_docs.tolist(), s_scores.tolist()))
         hybrid_out.append(fusion.fuse(dense, sparse)[:k])
 
+    Q_host = Q.cpu().numpy() if args.host else None
+    host_out = {}
+
     def step(s):
         if args.hybrid:
             return hybrid_step(s)
         i = s * B
+        if args.host:   # PCIe and the synchronisation are inside the step here, by definition of this mode
+            host_out["rows"], host_out["scores"], _ = store.search_batch_rows(Q_host[i:i + B], k)
+            return
         store.search_device(Q.data_ptr() + i * d * esz, B, k, out_rows.data_ptr() + i * k * esz,
                             out_scores.data_ptr() + i * k * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
@@ -214,6 +223,9 @@ def main():
         k = cand
     final_rows = (m_rows if ex is not None else out_rows)[-1].cpu().numpy().astype(np.uint32)
     final_scores = (m_scores if ex is not None else out_scores)[-1].cpu().numpy()
+    if args.host:
+        final_rows, final_scores = host_out["rows"][-1].astype(np.uint32), host_out["scores"][-1]
+        uncertified = 0   # the host entry repeats unfinished queries itself
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
     if world == 1:
         # the exact-order scan of the same query must return the same rows and score bits
@@ -265,6 +277,9 @@ def main():
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
                        "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma", 4: "bf16-prefilter", 5: "bf16-mirror"}[args.mode],
                        "bf16_mirror": bool(args.mirror),
+                       "entry": "host pointers (PCIe + synchronisation inside every step)" if args.host
+                                else "device-resident queries and results",
+                       "latency_us_per_call": 1e3 * ms_per_step if args.host else None,
                        "path_used": {1: "exact scan (f32, reference order)", 2: "streaming scan + exact re-score",
                                      3: "f32 matrix cores + exact re-score",
                                      4: "bf16 matrix-core prefilter + exact f32 scoring of candidates",
@@ -291,7 +306,7 @@ def main():
                                    "launches_timed": scan_launches, "queries_per_launch": b_launch,
                                    "algorithmic_bytes_per_launch": algo_bytes,
                                    "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9})
-        if world == 1 and not args.hybrid and not args.mirror and args.mode == 0:
+        if world == 1 and not args.hybrid and not args.mirror and args.mode == 0 and not args.host:
             result["with_bf16_mirror"] = mirror_leg(store, args, Q, out_rows, out_scores, out_n, status, n_local, d,
                                                     B, k, esz, sptr)
         if not args.no_cpu_baseline and world == 1:   # the CPU leg belongs to the single-GPU line only

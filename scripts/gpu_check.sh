@@ -21,6 +21,8 @@ for c in "$@"; do
     d4k) A="--rows 2000000 --dim 4096";; d4km) A="--rows 2000000 --dim 4096 --mirror";;
     d768) A="--rows 2000000 --dim 768";; d1536) A="--rows 1000000 --dim 1536";; d128) A="--rows 8000000 --dim 128";;
     1Meu) A="--rows 1000000 --steps 200 --metric euclidean";; 1Mdot) A="--rows 1000000 --steps 200 --metric dot";;
+    c1) A="--rows 10000 --host --steps 2000 --warmup 50";;
+    100k) A="--rows 100000 --steps 500 --warmup 20";; 10k) A="--rows 10000 --steps 1000 --warmup 20";;
     b32) A="--batch 32";; b32m) A="--batch 32 --mirror";;
     b256) A="--batch 256";; b256m) A="--batch 256 --mirror";;
     b4) A="--batch 4";; b4m) A="--batch 4 --mirror";; b2m) A="--batch 2 --mirror";;
