@@ -23,6 +23,7 @@ for c in "$@"; do
     1Meu) A="--rows 1000000 --steps 200 --metric euclidean";; 1Mdot) A="--rows 1000000 --steps 200 --metric dot";;
     c1) A="--rows 10000 --host --steps 2000 --warmup 50";;
     100k) A="--rows 100000 --steps 500 --warmup 20";; 10k) A="--rows 10000 --steps 1000 --warmup 20";;
+    b64m) A="--batch 64 --mirror";; b128m) A="--batch 128 --mirror";; b8m) A="--batch 8 --mirror";;
     b32) A="--batch 32";; b32m) A="--batch 32 --mirror";;
     b256) A="--batch 256";; b256m) A="--batch 256 --mirror";;
     b4) A="--batch 4";; b4m) A="--batch 4 --mirror";; b2m) A="--batch 2 --mirror";;
