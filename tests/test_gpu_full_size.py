@@ -113,3 +113,46 @@ def test_batch_configs_against_oracle(trag, oracle, n, d, B, seed):
     store.set_scan_mode(EXACT)
     r8, s8, _ = store.search_batch_rows(Q[:8], 10)
     assert np.array_equal(r8, rows[:8]) and s8.tobytes() == scores[:8].tobytes()
+
+
+@pytest.mark.parametrize("n,d,k", [(10_000_000, 384, 10), (2_000_000, 4096, 50)])
+def test_mirror_at_full_size_equals_exact_scan(trag, oracle, n, d, k):
+    """The bench default (10M x 384) and the C5 shape (2M x 4096, top 50) with the bf16 mirror:
+    single queries and a batch must return the exact scan's rows and score bits."""
+    store = _store(trag, d, n)
+    store.fill_synthetic(n, 1004)
+    Q = oracle.synth_rows(1104, 0, 12, d)
+    store.set_scan_mode(EXACT)
+    exact = [store.search_rows(q, k) for q in Q]
+    store.set_bf16_mirror(True)
+    store.set_scan_mode(0)
+    fallbacks = 0
+    for q, (er, es) in zip(Q, exact):
+        rows, scores = store.search_rows(q, k)
+        assert store.last_stats()["mode_used"] == 5
+        fallbacks += store.last_stats()["fallbacks"]
+        assert np.array_equal(rows, er) and scores.tobytes() == es.tobytes()
+    assert fallbacks == 0                      # the mirror pass itself finished every query
+    rb, sb, nb = store.search_batch_rows(Q, k)     # batch: matrix-core prefilter on the mirror (d = 384)
+    for b, (er, es) in enumerate(exact):
+        assert nb[b] == k and np.array_equal(rb[b], er) and sb[b].tobytes() == es.tobytes()
+
+
+def test_mirror_batch_256_uses_direct_to_lds_staging(trag, oracle):
+    """C3 with the mirror: 256 queries take the 256 x 256 tile whose operands go straight from
+    memory to LDS; results must equal the f32 matrix-core path's and the oracle's."""
+    n, d, B = 1_000_000, 768, 256
+    store = _store(trag, d, n)
+    store.fill_synthetic(n, 1003)
+    Q = oracle.synth_rows(1103, 0, B, d)
+    store.set_scan_mode(3)
+    ref = store.search_batch_rows(Q, 10)
+    store.set_bf16_mirror(True)
+    store.set_scan_mode(0)
+    got = store.search_batch_rows(Q, 10)
+    assert store.last_stats()["mode_used"] == 4 and store.last_stats()["fallbacks"] <= 2
+    assert np.array_equal(ref[0], got[0]) and ref[1].tobytes() == got[1].tobytes()
+    corpus = oracle.synth_rows(1003, 0, n, d)
+    for b in (0, 100, 255):
+        er, es = oracle.search(corpus, Q[b], 10, 0)
+        assert_same_ranking(got[0][b], got[1][b], er, es, f"C3 mirror {b}")
