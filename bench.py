@@ -302,6 +302,12 @@ def main():
         if traffic is not None:
             result["roofline"]["traffic"] = traffic.pop("bytes_per_launch")
             result["roofline"]["traffic_source"] = traffic
+        if world == 1 and not args.hybrid:
+            probe = store.stream_probe(3)   # plain contiguous read of the same rows, on this box, right now
+            if probe > 0:
+                result["roofline"]["measured_stream_read_GBps"] = probe
+                if result["roofline"]["bound"] == "hbm":
+                    result["roofline"]["frac_of_measured_stream_read"] = result["roofline"]["achieved"] / probe
         result["roofline"].update({"kernel": "scan (corpus pass)", "kernel_avg_ms": scan_avg_ms,
                                    "launches_timed": scan_launches, "queries_per_launch": b_launch,
                                    "algorithmic_bytes_per_launch": algo_bytes,

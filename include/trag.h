@@ -215,6 +215,12 @@ trag_status trag_store_set_scan_mode(trag_store *s, uint32_t scan_mode);
 trag_status trag_store_set_profiling(trag_store *s, int enabled);
 trag_status trag_store_scan_time(trag_store *s, double *total_ms, uint32_t *launches);
 
+/* Measurement aid: streams the store's rows once per repeat with plain contiguous
+ * 16-byte loads (no arithmetic) and reports the best rate in GB/s -- the memory
+ * system's streaming-read rate on this device, beside which the scan's rate can be
+ * read. No counterpart in the reference. */
+trag_status trag_store_stream_probe(trag_store *s, uint32_t repeats, double *gb_per_s);
+
 /* Counters of the last search on this handle (diagnostics). */
 typedef struct trag_search_stats {
     uint32_t mode_used;      /* trag_scan_mode actually run */

@@ -75,6 +75,7 @@ SIGNATURES = {
     "trag_store_set_bf16_mirror": (C.c_int, [_H, C.c_int]),
     "trag_store_has_bf16_mirror": (C.c_int, [_H]),
     "trag_store_scan_time": (C.c_int, [_H, C.POINTER(C.c_double), _u32p]),
+    "trag_store_stream_probe": (C.c_int, [_H, C.c_uint32, C.POINTER(C.c_double)]),
     "trag_store_read_rows": (C.c_int, [_H, C.c_uint64, C.c_uint64, _fp]),
     "trag_fuse": (C.c_int, [C.c_uint32, C.c_float, _u64p, _fp, C.c_uint32, _u64p, _fp, C.c_uint32,
                             _u64p, _fp, _u32p]),

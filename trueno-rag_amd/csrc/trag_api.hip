@@ -937,6 +937,34 @@ trag_status trag_store_set_bf16_mirror(trag_store* s, int enabled) {
 
 int trag_store_has_bf16_mirror(const trag_store* s) { return s && s->d_mirror ? 1 : 0; }
 
+trag_status trag_store_stream_probe(trag_store* s, uint32_t repeats, double* gb_per_s) {
+    if (!s || !gb_per_s) return fail(TRAG_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    *gb_per_s = 0.0;
+    if (s->n_rows == 0) return TRAG_OK;
+    DeviceGuard guard(s->device);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    hipError_t e = hipEventCreate(&e1);
+    if (e != hipSuccess) { (void)hipEventDestroy(e0); return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
+    const uint64_t n_floats = s->n_rows * s->cfg.dim;
+    float best_ms = 0.0f;
+    for (uint32_t r = 0; r < std::max<uint32_t>(repeats, 1) && e == hipSuccess; ++r) {
+        e = hipEventRecord(e0, s->stream);
+        if (e == hipSuccess) e = launch_stream_probe(s->d_rows, n_floats, s->d_vmax_sq, s->stream);  // (the sink is never written)
+        if (e == hipSuccess) e = hipEventRecord(e1, s->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && (best_ms == 0.0f || ms < best_ms)) best_ms = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(TRAG_DEVICE_ERROR, std::string("stream probe: ") + hipGetErrorString(e));
+    if (best_ms > 0.0f) *gb_per_s = (double)(n_floats / 4 * 16) / (best_ms * 1e-3) / 1e9;
+    return TRAG_OK;
+}
+
 trag_status trag_store_set_profiling(trag_store* s, int enabled) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);

@@ -1586,6 +1586,31 @@ vmax_kernel(const float* __restrict__ rows, unsigned long long n, uint32_t d,
         atomicMax(reinterpret_cast<unsigned int*>(vmax_sq), __float_as_uint(best));
 }
 
+// Reference point for the roofline figures: a plain contiguous stream over the same memory,
+// 16-byte non-temporal loads, eight per thread in flight, nothing but an add per load.
+__global__ void __launch_bounds__(256)
+stream_probe_kernel(const v4f* __restrict__ p, unsigned long long n4, float* __restrict__ sink) {
+    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256ull * 8ull;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull * 8ull + threadIdx.x; i < n4; i += stride) {
+        v4f x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned long long j = i + (unsigned long long)u * 256ull;
+            x[u] = j < n4 ? __builtin_nontemporal_load(p + j) : acc;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += x[u];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;  // keeps the loads alive
+}
+
+hipError_t launch_stream_probe(const float* d_rows, uint64_t n_floats, float* d_sink, hipStream_t st) {
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<const v4f*>(d_rows),
+                       (unsigned long long)(n_floats / 4), d_sink);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------

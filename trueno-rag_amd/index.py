@@ -199,6 +199,12 @@ class VectorStore:
         _abi.check(_abi.lib().trag_store_scan_time(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def stream_probe(self, repeats: int = 3) -> float:
+        """GB/s of a plain contiguous read of the store's rows (a reference point for rooflines)."""
+        g = C.c_double()
+        _abi.check(_abi.lib().trag_store_stream_probe(self._h, repeats, C.byref(g)))
+        return g.value
+
     def search_device(self, d_queries_ptr: int, n_queries: int, k: int, d_rows_ptr: int, d_scores_ptr: int,
                       d_n_ptr: int, d_status_ptr: int = 0, stream: int = 0) -> None:
         """Asynchronous search on device-resident queries (raw device addresses)."""
