@@ -67,6 +67,9 @@ __device__ __forceinline__ float finish_score(float acc0, float acc1, float na) 
 // last-arriving workgroup (agent-scope release + ticket per workgroup). The
 // 256 release fences and a 256-thread select cost more than the launch boundary
 // they remove: step 0.278 ms vs 0.256 ms at 1M x 384, 2.357 vs 2.329 at 10M x 384.
+// The outputs are not what holds the scan below the probe: with the histogram
+// atomics, the keys[] stores and the tombstone reads all compiled out the scan
+// takes 2.264 ms instead of 2.330 (10M x 384).
 // ---------------------------------------------------------------------------
 template <int METRIC, int EX_CW /* chunk width in floats: 32 or 64 */, bool NT, int WPB /* waves per workgroup */,
           bool ROLL /* refill load by load instead of chunk by chunk */>
