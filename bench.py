@@ -85,13 +85,30 @@ def main():
     if (world == 1 and not args.no_pmc and not args.hybrid and not args.host and not profiled
             and not os.environ.get("TRAG_BENCH_CHILD")):
         traffic = pmc_traffic(args)
+    # TRAG_BENCH_ONE_GPU=1: rehearsal of the N > 1 code path on a one-GPU box — every rank uses
+    # cuda:0 and the collectives go through gloo (RCCL refuses two ranks on one device). The
+    # numbers of such a run mean nothing; it exists to exercise the sharded step end to end.
+    one_gpu = bool(os.environ.get("TRAG_BENCH_ONE_GPU"))
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     pkg = load_package()
     L = pkg.lib()
 
+    def stage(msg):
+        if os.environ.get("TRAG_BENCH_DEBUG"):
+            print(f"[debug] rank {rank}: {msg}", file=sys.stderr, flush=True)
+
+    if os.environ.get("TRAG_BENCH_DEBUG"):   # a stuck run names the line it is stuck on, then exits
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("TRAG_BENCH_WATCHDOG_S", "600")), exit=True)
+    stage("process group up")
     n_total, d, k = args.rows, args.dim, args.k
     per = (n_total + world - 1) // world
     row0 = rank * per
@@ -186,9 +203,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    stage("store filled, buffers allocated")
     for i in range(args.warmup):
         step(i)
+        stage(f"warmup step {i} enqueued")
     fence()
+    stage("warmup done")
     # an event pair costs ~6 us of stream time: on sub-millisecond scans time every 4th launch only
     store.set_profiling(0 if os.environ.get("TRAG_BENCH_NO_PROFILE") else (4 if args.steps >= 40 else 1))
     import gc
@@ -206,6 +226,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
+    stage("timed steps done")
     if os.environ.get("TRAG_BENCH_DEBUG"):
         print(f"[debug] loop {1e3 * t_loop:.2f} ms, fence {1e3 * (elapsed - t_loop):.2f} ms", file=sys.stderr)
     scan_ms, scan_launches = store.scan_time()
@@ -227,6 +248,19 @@ def main():
         final_rows, final_scores = host_out["rows"][-1].astype(np.uint32), host_out["scores"][-1]
         uncertified = 0   # the host entry repeats unfinished queries itself
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
+    if world > 1:
+        # the device merge of the last query against a host merge of every rank's own list
+        # (descending score, ascending global row; gathered as plain Python objects)
+        mine = (out_rows[-1].cpu().numpy().astype(np.int64) + row0, out_scores[-1].cpu().numpy(),
+                int(out_n[-1].item()))
+        lists = [None] * world
+        dist.all_gather_object(lists, mine)
+        g_rows = np.concatenate([r[:n] for r, _, n in lists])
+        g_scores = np.concatenate([sc[:n] for _, sc, n in lists])
+        order = np.lexsort((g_rows, -g_scores.astype(np.float64)))[:k]
+        parity["device_merge_equals_host_merge"] = bool(
+            np.array_equal(g_rows[order], final_rows.astype(np.int64)[:len(order)])
+            and g_scores[order].tobytes() == final_scores[:len(order)].tobytes())
     if world == 1:
         # the exact-order scan of the same query must return the same rows and score bits
         store.set_scan_mode(1)
@@ -268,7 +302,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if one_gpu else ""),
             "config": {"workload": (f"{n_total}x{d} fp32 corpus in HBM, hybrid step: dense cosine top-50 + BM25 "
                                     f"top-50 over {n_total} synthetic documents (both on the GPU) -> RRF(60) on "
                                     f"the host -> top-{args.k}") if args.hybrid else

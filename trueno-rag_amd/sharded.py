@@ -41,6 +41,13 @@ class ShardExchange:
         self.device = device if device is not None else torch.device("cpu")
         self.pack = torch.zeros(max_queries * self.rec, dtype=torch.int32, device=self.device)
         self.gathered = torch.zeros(self.world * max_queries * self.rec, dtype=torch.int32, device=self.device)
+        # device records over a gloo group (several ranks sharing one GPU, tests): the gather is
+        # staged through pinned host buffers, since gloo moves host memory
+        self.host_staged = (self.device.type == "cuda" and self.world > 1
+                            and dist.get_backend(group) == "gloo")
+        if self.host_staged:
+            self.h_pack = torch.zeros(max_queries * self.rec, dtype=torch.int32).pin_memory()
+            self.h_gathered = torch.zeros(self.world * max_queries * self.rec, dtype=torch.int32).pin_memory()
 
     def exchange(self, rows, scores, counts, row0, out_rows, out_scores, out_counts, stream_ptr=0):
         """rows/scores: [B, k] (int32 local row ids / float32), counts: [B] int32 —
@@ -62,7 +69,15 @@ class ShardExchange:
             p[:, :k] = scores.reshape(B, k).view(t.int32)
             p[:, k:2 * k] = rows.reshape(B, k) + row0
             p[:, 2 * k] = counts.reshape(B)
-        if self.world > 1:
+        if self.host_staged:
+            stream = t.cuda.ExternalStream(stream_ptr) if stream_ptr else t.cuda.current_stream()
+            with t.cuda.stream(stream):
+                hp, hg = self.h_pack[:B * rec], self.h_gathered[:self.world * B * rec]
+                hp.copy_(pack, non_blocking=True)
+                stream.synchronize()
+                self.dist.all_gather_into_tensor(hg, hp, group=self.group)
+                gathered.copy_(hg, non_blocking=True)
+        elif self.world > 1:
             self.dist.all_gather_into_tensor(gathered, pack, group=self.group)
         else:
             gathered.copy_(pack)
