@@ -15,6 +15,21 @@
 // keys, the tile / wave maxima and 64 LDS histogram increments, as the other
 // scans. Algorithmic bytes per launch: N * d * 2 (+ 4 N of squared norms for
 // cosine, + 4 N of keys written).
+//
+// Where the time goes (MI355X, 10M x 384, 7.68 GB per launch; scripts/diag_stream.hip holds
+// the standalone probes): the load pattern alone, with the conversions, FMAs and butterflies
+// but no outputs, streams at 7.1 TB/s (1.08 ms). This kernel takes 1.25 ms. Compiling the
+// outputs out one at a time: without the per-row key store 1.16 ms, also without the tile
+// maxima 1.153, also without the norm / tombstone reads 1.149, also without the LDS
+// histogram 1.147. The key store is 0.5 % of the bytes and 8 % of the time: the cost follows
+// the number of tiles stored (every 4th tile: a quarter of it), not the instruction count or
+// the batching (16 tiles buffered in LDS and flushed together: no change), and non-temporal or
+// system-scope stores recover under half of it in the probe and nothing here. Measured and
+// rejected as well: an unconditional refill with a scheduling barrier after each load group
+// (exactly 12 + 12 loads in flight, waits 23..12: 1.253 ms), and storing only the tiles whose
+// maximum reaches the coarse bin of the wave's k-th best tile maximum, shared through one
+// word with atomic max (bins of a quarter binade plus the 2 eps margin leave ~3/4 of the
+// tiles above the bound; polling the word every tile cost 17 %).
 #include "trag_device.h"
 #include "trag_internal.h"
 #include "trag_scan_common.h"
