@@ -227,6 +227,8 @@ typedef struct trag_search_stats {
     uint32_t candidates;     /* rows that reached the final sort */
     uint32_t refine_levels;  /* radix-select levels needed (1..3) */
     uint32_t fallbacks;      /* queries repeated with the exact scan */
+    uint32_t keys_kept_from; /* ordered key below which the scan skipped its per-row key stores (long
+                                single-query scans keep only what the select can read); 0: none skipped */
 } trag_search_stats;
 trag_status trag_store_last_stats(const trag_store *s, trag_search_stats *out);
 

@@ -43,7 +43,7 @@ class BM25Config(C.Structure):
 
 class SearchStats(C.Structure):
     _fields_ = [("mode_used", C.c_uint32), ("candidates", C.c_uint32),
-                ("refine_levels", C.c_uint32), ("fallbacks", C.c_uint32)]
+                ("refine_levels", C.c_uint32), ("fallbacks", C.c_uint32), ("keys_kept_from", C.c_uint32)]
 
 
 # name -> (restype, argtypes); the single source the symbol-export test iterates over.

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -95,6 +96,8 @@ struct trag_store {
     uint32_t refine_calls = 0, select_calls = 0;  // calls that needed it / all calls, while it is not the plan
     uint32_t* h_events = nullptr;  // host-pinned word the select kernels bump when a query needs it
     uint64_t one_wg_queries = 0;   // queries enqueued with the one-workgroup select so far
+    uint32_t scan_epoch = 0;       // tag of the last scan with sparse key stores (trag_scan_common.h)
+    int sparse_keys = -1;          // 1: single-query scans skip the key stores no later stage can read
     unsigned long long* d_sort = nullptr;  // large-k path: rank keys of every row, padded to 2^m
     unsigned long long sort_cap = 0;
     // staging for the host-pointer entry points
@@ -214,6 +217,11 @@ trag_status ensure_scratch(trag_store* s) {
         s->scratch.ctl = reinterpret_cast<SearchCtl*>(s->zero_block);
         s->scratch.hist = reinterpret_cast<uint32_t*>(static_cast<char*>(s->zero_block) + ctl_bytes);
         if (!s->scratch.wmax) HIP_TRY(hipMalloc(&s->scratch.wmax, WMAX_CAP * sizeof(uint32_t)));
+        if (!s->scratch.wbest) {
+            HIP_TRY(hipMalloc(&s->scratch.wbest, SPARSE_WAVES * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(s->scratch.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+        }
         HIP_TRY(hipMalloc(&s->scratch.keys, (size_t)s->cap_rows * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&s->scratch.tmax, ((size_t)s->cap_rows / 64 + 1) * sizeof(uint32_t)));
         s->keys_cap = s->cap_rows;
@@ -412,6 +420,26 @@ hipError_t scan_timer_begin(trag_store* s, hipStream_t st, hipEvent_t* closing) 
 
 // Enqueue the pipeline for n_queries device-resident queries on `st`.
 // Caller holds s->mu, has set the device and made sure n_live > 0 and k > 0.
+
+// Tags the next single-query scan for the sparse key stores (the tag tells this scan's
+// wbest[] entries from older ones; 0 = off: the multi-level select reads every key).
+// TRAG_SPARSE_KEYS=0 turns them off for the process.
+static hipError_t next_scan_epoch(trag_store* s, bool allowed, hipStream_t st) {
+    if (s->sparse_keys < 0) {
+        const char* e = getenv("TRAG_SPARSE_KEYS");
+        s->sparse_keys = (e && e[0] == '0') ? 0 : 1;
+    }
+    s->scratch.epoch = 0;
+    if (!s->sparse_keys || !allowed || !s->scratch.wbest) return hipSuccess;
+    hipError_t err = hipSuccess;
+    if (++s->scan_epoch == 0u) {   // wrapped: forget every old tag
+        s->scan_epoch = 1;
+        err = hipMemsetAsync(s->scratch.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st);
+    }
+    s->scratch.epoch = s->scan_epoch;
+    return err;
+}
+
 trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_queries, uint32_t k,
                            uint32_t mode, uint32_t* d_out_rows, float* d_out_scores,
                            uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
@@ -427,6 +455,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         const uint32_t ev = *static_cast<volatile uint32_t*>(s->h_events);
         if (ev >= 4 && (uint64_t)ev * 2 >= s->one_wg_queries) s->full_select = true;
     }
+    s->scratch.epoch = 0;  // sparse key stores: only the single-query scans below switch them on
     if (k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP) {
         // More results than the one-workgroup sort holds: exact scan, then a
         // global sort of every row's rank key (rare; the reference's callers ask
@@ -504,6 +533,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             hipEvent_t e1 = nullptr;
             HIP_TRY(scan_timer_begin(s, st, &e1));
             uint32_t n_waves = 0;
+            HIP_TRY(next_scan_epoch(s, !s->full_select, st));
             HIP_TRY(launch_scan_mirror(s->d_mirror, q, s->d_norm2, a, s->scratch, need_m, k_eff, s->d_vmax_sq,
                                        &n_waves, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -553,6 +583,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             continue;
         }
         s->last_ctl = s->scratch.ctl;
+        HIP_TRY(next_scan_epoch(s, !rescore && !s->full_select, st));
         if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
         else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -623,7 +654,7 @@ void trag_store_destroy(trag_store* s) {
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->d_mirror,
                     s->batch.qpad, s->batch.ctls, s->batch.keys, s->batch.tmax, s->batch.cand,
                     s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys,
-                    s->zero_block, s->scratch.cand, s->scratch.ckeys, s->scratch.keys, s->scratch.tmax, s->scratch.wmax,
+                    s->zero_block, s->scratch.cand, s->scratch.ckeys, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->scratch.wbest,
                     s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax,
                     s->d_sort, s->d_q, s->d_out_block};
     for (void* p : ptrs)
@@ -890,6 +921,7 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
         s->stats.candidates = ctl.expect;
         s->stats.refine_levels = ctl.levels;
     }
+    s->stats.keys_kept_from = (mode == TRAG_SCAN_EXACT || mode == TRAG_SCAN_MIRROR) ? ctl.keep_key : 0u;
     return TRAG_OK;
 }
 

@@ -17,6 +17,13 @@ constexpr uint32_t CAND_CAP = 4096;
 constexpr uint32_t STREAM_SLACK = 32;
 // Most waves a scan grid may have (sizes the per-wave maxima).
 constexpr uint32_t WMAX_CAP = 16384;
+// Scan waves that can take part in the sparse key stores (see trag_scan_common.h): one entry each.
+constexpr uint32_t SPARSE_WAVES = 1024;
+// ... and the scans long enough for them to pay: the polls cost a wave ~2 us each and the first
+// tiles of every wave are stored regardless. MI355X, scan time with / without: exact 10M x 384
+// 2.262 / 2.382 ms, mirror 10M x 384 1.170 / 1.262; switched on for every size: 1M x 384 exact
+// 0.249 / 0.238, 1.25M x 384 0.303 / 0.295, 2M x 768 0.912 / 0.917, 2M x 4096 unchanged.
+inline bool sparse_scan_pays(uint32_t n_tiles, uint32_t n_waves) { return n_waves > 0 && n_tiles / n_waves >= 40u; }
 
 // Final status written per query.
 constexpr uint32_t ST_OK = 0;
@@ -43,6 +50,7 @@ struct SearchCtl {
     uint32_t status;
     uint32_t levels;     // radix levels the last select needed (diagnostics)
     uint32_t n_waves;    // waves of the scan grid: tile t was scanned by wave t % n_waves
+    uint32_t keep_key;   // sparse key stores: the bound the select raised its cut to (0: none; diagnostics)
 };
 
 // Device scratch of one in-flight query.
@@ -58,6 +66,8 @@ struct Scratch {
     uint32_t* tmax;      // capacity rows / 64: largest key of each 64-row tile
     uint32_t* events;    // host-pinned, device-visible word (may be null): queries whose one-workgroup
                          // select asked for the multi-level form; the host reads it without synchronising
+    unsigned long long* wbest = nullptr;  // SPARSE_WAVES entries (scan epoch << 32) | best key a wave has published
+    uint32_t epoch = 0;  // tag of the current scan in wbest[]; 0: the scan stores every row's key
 };
 
 // Device scratch of a block of queries on the batched (matrix-core) path.

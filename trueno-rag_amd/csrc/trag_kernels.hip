@@ -67,9 +67,10 @@ __device__ __forceinline__ float finish_score(float acc0, float acc1, float na) 
 // last-arriving workgroup (agent-scope release + ticket per workgroup). The
 // 256 release fences and a 256-thread select cost more than the launch boundary
 // they remove: step 0.278 ms vs 0.256 ms at 1M x 384, 2.357 vs 2.329 at 10M x 384.
-// The outputs are not what holds the scan below the probe: with the histogram
-// atomics, the keys[] stores and the tombstone reads all compiled out the scan
-// takes 2.264 ms instead of 2.330 (10M x 384).
+// With the histogram atomics, the keys[] stores and the tombstone reads all compiled
+// out the scan takes 2.264 ms instead of 2.330 (10M x 384); the keys[] stores are most
+// of that, and long scans skip the ones no later stage can read (sparse key stores,
+// trag_scan_common.h: 2.262 ms against 2.382 on the same, slower, device).
 // ---------------------------------------------------------------------------
 template <int METRIC, int EX_CW /* chunk width in floats: 32 or 64 */, bool NT, int WPB /* waves per workgroup */,
           bool ROLL /* refill load by load instead of chunk by chunk */>
@@ -79,7 +80,7 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
                      uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
                      SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
                      uint32_t* __restrict__ tmax, uint32_t* __restrict__ wmax,
-                     uint32_t* __restrict__ hist) {
+                     uint32_t* __restrict__ hist, unsigned long long* __restrict__ wbest, uint32_t epoch) {
     constexpr int EX_STRIDE = EX_CW + 4;  // padded LDS row stride in floats
     constexpr int LPR = EX_CW / 4;        // lanes that cover one row's chunk with 16-byte loads
     constexpr int RPL = 64 / LPR;         // rows covered by one wave-wide load
@@ -126,8 +127,15 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
         const float na = METRIC == 0 ? na_sh : 0.0f;
         uint32_t wave_best = 0u;  // largest key over all tiles of this wave
         const uint32_t wave_id = blockIdx.x * (uint32_t)WPB + wid;
+        // sparse key stores (trag_scan_common.h): exact keys, so the bound is the need-th
+        // largest published key itself
+        const bool track = epoch != 0u && need >= 1u && need <= 64u && n_waves <= SPARSE_WAVES;
+        uint32_t keep_key = 0u, tiles_done = 0u;
+        unsigned long long polled[16];
         while (t < n_tiles) {
             float acc0 = 0.0f, acc1 = 0.0f;
+            const bool poll = track && sparse_poll_at(tiles_done);
+            if (poll) sparse_poll_issue(wbest, lane, polled);   // (used after the tile)
             for (uint32_t c = 0; c < n_chunks; ++c) {
                 // Stage chunk c (the reads of the previous chunk are older DS ops of this wave) and
                 // refill. ROLL: as soon as load i of this chunk has landed and gone to LDS, load i of
@@ -184,13 +192,23 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
                     key = score_key(finish_score<METRIC>(acc0, acc1, na));
                     atomicAdd(&lhist[key >> 21], 1u);
                 }
-                keys[row] = key;
             }
             const uint32_t tm = wave_max_u32(key);
+            wave_best = tm > wave_best ? tm : wave_best;
+            if (track) {
+                ++tiles_done;
+                if (sparse_publish_at(tiles_done) && lane == 0)
+                    __hip_atomic_store(wbest + wave_id, ((unsigned long long)epoch << 32) | wave_best,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (poll) {
+                    const uint32_t kk = sparse_poll_value(polled, epoch, need);
+                    keep_key = kk > keep_key ? kk : keep_key;
+                }
+            }
+            if (row < n_rows && tm >= keep_key) keys[row] = key;
             if (lane == 0) {
                 tmax[t] = tm;
             }
-            wave_best = tm > wave_best ? tm : wave_best;
             t += n_waves;
         }
         if (lane == 0) wmax[wave_id] = wave_best;
@@ -900,7 +918,8 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                     const uint32_t* __restrict__ wmax, uint32_t* __restrict__ out_rows,
                     float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
                     uint32_t* __restrict__ out_status, MultiStride ms, uint32_t out_stride,
-                    uint32_t* __restrict__ events) {
+                    uint32_t* __restrict__ events, const unsigned long long* __restrict__ wbest,
+                    uint32_t epoch) {
     // one workgroup per query of a multi-query scan (blockIdx.x = query; strides 0 for one query)
     {
         const size_t b = blockIdx.x;
@@ -918,13 +937,26 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t hit[CAND_CAP];
     __shared__ uint32_t sh[24];
-    __shared__ uint32_t n_hit_sh, n_cand_sh, n_thit_sh;
+    __shared__ uint32_t n_hit_sh, n_cand_sh, n_thit_sh, keep_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     // independent of the threshold: this thread's share of the per-wave maxima
     const uint32_t my_wmax = ((uint32_t)tid < n_waves && (uint32_t)tid < n_tiles) ? wmax[tid] : 0u;
     float na = 0.0f;
     if (RESCORE) na = ctl->na;
+    // A scan with sparse key stores (trag_scan_common.h; single exact queries only) kept the keys
+    // of the tiles that reach the need-th largest of the keys its waves published; at least
+    // `need` rows lie at or above that key, so the cut starts there and skipped tiles are never read.
+    if (wid == 0) {
+        uint32_t keep = 0u;
+        if (epoch != 0u && wbest) {
+            unsigned long long e[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = wbest[i * 64 + lane];
+            keep = sparse_poll_value(e, epoch, need);
+        }
+        if (lane == 0) keep_sh = keep;
+    }
     uint32_t b1, above1;
     uint32_t inbin1;
     find_bin<1024>(hist, need, b1, above1, sh, &inbin1);
@@ -933,10 +965,10 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     if (expect > CAND_CAP) {
         status = ST_NEED_REFINE;
     } else {
-        const uint32_t t_key = b1 << 21;
-        const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
         if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; n_thit_sh = 0; }
-        __syncthreads();
+        __syncthreads();  // (find_bin's barriers already ordered keep_sh)
+        const uint32_t t_key = max(b1 << 21, keep_sh);
+        const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
         if (expect <= CAND_CAP / 2) {
             gather_flat(t_min, 0xFFFFFFFFu, RESCORE, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit,
                         &n_hit_sh, &n_thit_sh, &n_cand_sh);
@@ -1059,6 +1091,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         ctl->expect = C;
         ctl->t_key = b1 << 21;
         ctl->levels = 1;
+        ctl->keep_key = keep_sh;
         ctl->status = status;
         if (out_status) *out_status = status;
         if (status == ST_NEED_REFINE && events)
@@ -1172,19 +1205,35 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
                      SearchCtl* __restrict__ ctl, uint32_t* __restrict__ hist,
                      const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
                      const uint32_t* __restrict__ wmax, uint32_t* __restrict__ cand,
-                     uint32_t* __restrict__ events) {
+                     uint32_t* __restrict__ events, const unsigned long long* __restrict__ wbest,
+                     uint32_t epoch) {
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t hit[CAND_CAP];
     __shared__ uint32_t sh[24];
-    __shared__ uint32_t n_hit_sh, n_cand_sh, n_thit_sh, extra_sh, nf_sh, ns_sh, akey_sh;
+    __shared__ uint32_t n_hit_sh, n_cand_sh, n_thit_sh, extra_sh, nf_sh, ns_sh, akey_sh, keep_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     const uint32_t my_wmax = ((uint32_t)tid < n_waves && (uint32_t)tid < n_tiles) ? wmax[tid] : 0u;
     // (the control block's fields are fetched up front: their latency hides behind the histogram scan)
     const float na = ctl->na, nsq = ctl->na_sq, vmax = sqrtf(ctl->vmax_sq);
     uint32_t b1, above1, inbin1;
+    // A scan with sparse key stores (trag_scan_common.h) kept the keys of the tiles that reach
+    // the bound below, which this stage recomputes from the waves' published keys: at least k
+    // bounded rows lie at or above it and T never falls under it, so the cut starts there.
+    if (wid == 0) {
+        uint32_t keep = 0u;
+        if (epoch != 0u && wbest) {
+            unsigned long long e[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) e[i] = wbest[i * 64 + lane];
+            const float eps0 = mirror_eps<METRIC>(d, na, vmax);
+            if ((nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f)) && eps0 < INFINITY)
+                keep = sparse_keep_key(sparse_poll_value(e, epoch, k), 2.02f * eps0 * 1.01f);
+        }
+        if (lane == 0) keep_sh = keep;
+    }
     find_bin<1024>(hist, need, b1, above1, sh, &inbin1);
-    const uint32_t expect = above1 + inbin1;
+    const uint32_t expect = above1 + inbin1;  // (an upper bound when the cut is raised to keep_sh)
     if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; n_thit_sh = 0; extra_sh = 0; nf_sh = 0; ns_sh = 0; akey_sh = 0; }
     __syncthreads();
     // append the rows with lo <= key < hi to sk[] (through the wave maxima, then the tile
@@ -1236,9 +1285,10 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
     if (expect > CAND_CAP) {
         status = ST_NEED_REFINE;
     } else {
-        const uint32_t t_key = b1 << 21;
+        const uint32_t t_key = max(b1 << 21, keep_sh);
         const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
         const bool all_in = t_min == 1u;                 // every live row is a candidate
+        const uint32_t b_top = (t_min + 0x1FFFFFu) >> 21;  // coarse bins below this one lie wholly under the cut
         gather(t_min, 0xFFFFFFFFu, expect);  // (+inf is the largest key a row can carry: 0xFF800000)
         C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
         // The k-th best approximate key by counting ranks (all threads read the same sk[j] at
@@ -1285,12 +1335,12 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
         // their number before anything is gathered.
         if (status == ST_OK && !all_in && T_key < t_min) {
             const uint32_t cut2 = T_key >> 21;
-            if (b1 - cut2 > 64u) {
+            if (b_top - cut2 > 64u) {
                 status = ST_UNCERTIFIED;
             } else {
                 if (wid == 0) {
-                    const uint32_t bin = b1 - 1u - (uint32_t)lane;
-                    uint32_t h = (bin >= cut2 && bin < b1) ? hist[bin] : 0u;
+                    const uint32_t bin = b_top - 1u - (uint32_t)lane;
+                    uint32_t h = (bin >= cut2 && bin < b_top) ? hist[bin] : 0u;
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o);
                     if (lane == 0) { extra_sh = h; n_hit_sh = 0; n_thit_sh = 0; }
@@ -1324,6 +1374,7 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
         ctl->expect = C;
         ctl->t_key = T_key;
         ctl->levels = 1;
+        ctl->keep_key = keep_sh;
         ctl->status = status;
         if (status == ST_NEED_REFINE && events)
             __hip_atomic_fetch_add(events, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1642,16 +1693,17 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
                 (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         }
         const uint32_t grid = grid_for(n_tiles, 4, (uint32_t)n_cu);
+        const uint32_t ep = (s.wbest && sparse_scan_pays(n_tiles, grid * 4u)) ? s.epoch : 0u;
         // load-by-load refill pays only for short rows (same run, MI355X: d = 128 +6 %, 384 -2 %,
         // 768 / 1536 / 4096 within noise)
         if (a.dim <= 256)
             hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, true>), dim3(grid), dim3(256), 0, st,
                                a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
-                               s.tmax, s.wmax, s.hist);
+                               s.tmax, s.wmax, s.hist, s.wbest, ep);
         else
             hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, false>), dim3(grid), dim3(256), 0, st,
                                a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
-                               s.tmax, s.wmax, s.hist);
+                               s.tmax, s.wmax, s.hist, s.wbest, ep);
         return grid * 4u;
     } else {
         const uint32_t grid = grid_for(a.n_rows, 256, 256 * 8);
@@ -1811,11 +1863,13 @@ static void select_final_dispatch(const float* d_q, const ScanArgs& a, const Scr
     if (rescore)
         hipLaunchKernelGGL((select_final_kernel<METRIC, true>), dim3(n_queries), dim3(1024), 0, st, a.corpus,
                            d_q, a.n_rows, a.dim, live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax,
-                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride, s.events);
+                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride, s.events,
+                           (const unsigned long long*)nullptr, 0u);
     else
         hipLaunchKernelGGL((select_final_kernel<METRIC, false>), dim3(n_queries), dim3(1024), 0, st, a.corpus,
                            d_q, a.n_rows, a.dim, live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax,
-                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride, s.events);
+                           s.wmax, d_out_rows, d_out_scores, d_out_n, d_status, ms, out_stride, s.events,
+                           n_queries == 1 ? s.wbest : nullptr, (n_queries == 1 && s.wbest) ? s.epoch : 0u);
 }
 
 hipError_t launch_select_final(const float* d_q, const ScanArgs& a, const Scratch& s, bool rescore,
@@ -1862,7 +1916,7 @@ hipError_t launch_select_mirror(const float* d_q, const ScanArgs& a, const Scrat
         } else {                                                                                           \
             hipLaunchKernelGGL(select_mirror_kernel<METRIC>, dim3(1), dim3(1024), 0, st, a.n_rows, a.dim,  \
                                live, need, k, n_waves, s.ctl, s.hist, s.keys, s.tmax, s.wmax, s.cand,      \
-                               s.events);                                                                  \
+                               s.events, s.wbest, s.wbest ? s.epoch : 0u);                                 \
         }                                                                                                  \
         hipLaunchKernelGGL(rescore_wave_kernel<METRIC>, dim3(256), dim3(256), 0, st, a.corpus, d_q,        \
                            a.n_rows, a.dim, s.ctl, s.cand, s.ckeys);                                       \

@@ -18,18 +18,19 @@
 //
 // Where the time goes (MI355X, 10M x 384, 7.68 GB per launch; scripts/diag_stream.hip holds
 // the standalone probes): the load pattern alone, with the conversions, FMAs and butterflies
-// but no outputs, streams at 7.1 TB/s (1.08 ms). This kernel takes 1.25 ms. Compiling the
-// outputs out one at a time: without the per-row key store 1.16 ms, also without the tile
-// maxima 1.153, also without the norm / tombstone reads 1.149, also without the LDS
-// histogram 1.147. The key store is 0.5 % of the bytes and 8 % of the time: the cost follows
-// the number of tiles stored (every 4th tile: a quarter of it), not the instruction count or
-// the batching (16 tiles buffered in LDS and flushed together: no change), and non-temporal or
-// system-scope stores recover under half of it in the probe and nothing here. Measured and
-// rejected as well: an unconditional refill with a scheduling barrier after each load group
-// (exactly 12 + 12 loads in flight, waits 23..12: 1.253 ms), and storing only the tiles whose
-// maximum reaches the coarse bin of the wave's k-th best tile maximum, shared through one
-// word with atomic max (bins of a quarter binade plus the 2 eps margin leave ~3/4 of the
-// tiles above the bound; polling the word every tile cost 17 %).
+// but no outputs, streams at 7.1 TB/s (1.08 ms). With every row's key stored this kernel takes
+// 1.26 ms; compiling the outputs out one at a time: without the per-row key store 1.16 ms, also
+// without the tile maxima 1.153, also without the norm / tombstone reads 1.149, also without
+// the LDS histogram 1.147. The key store is 0.5 % of the bytes and 8 % of the time: the cost
+// follows the number of tiles stored (every 4th tile: a quarter of it), not the instruction
+// count or the batching (16 tiles buffered in LDS and flushed together: no change), and
+// non-temporal or system-scope stores recover under half of it in the probe and nothing here.
+// Hence the sparse key stores (trag_scan_common.h): 1.17 ms on long scans.
+// Measured and rejected: an unconditional refill with a scheduling barrier after each load
+// group (exactly 12 + 12 loads in flight, waits 23..12: 1.253 ms); a bound per coarse bin from
+// each wave's own k best tile maxima shared through one word with atomic max (bins of a
+// quarter binade plus the 2 eps margin leave ~3/4 of the tiles above the bound; polling the
+// word every tile cost 17 %).
 #include "trag_device.h"
 #include "trag_internal.h"
 #include "trag_scan_common.h"
@@ -96,22 +97,26 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
                    const float* __restrict__ norm2, const uint32_t* __restrict__ dead, uint32_t n_rows,
                    uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
                    SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys, uint32_t* __restrict__ tmax,
-                   uint32_t* __restrict__ wmax, uint32_t* __restrict__ hist) {
+                   uint32_t* __restrict__ wmax, uint32_t* __restrict__ hist,
+                   unsigned long long* __restrict__ wbest, uint32_t epoch) {
     constexpr int ITERS = G;      // iterations per 64-row tile; iteration i takes rows i, G + i, 2G + i, ... of the tile
     constexpr int D16 = G * NV;   // 16-byte pieces per row
     constexpr uint32_t D = 8u * D16;
     static_assert(ITERS % U == 0, "unroll must divide the tile");
     __shared__ v4f qs[2 * D16];
     __shared__ uint32_t lhist[HIST_BINS];
-    __shared__ float na_sh;
+    __shared__ float na_sh, nsq_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // sparse key stores (trag_scan_common.h): on when the launcher passes an epoch
+    const bool track = epoch != 0u && k >= 1u && k <= 64u && gridDim.x * 4u <= SPARSE_WAVES;
     for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
     for (int i = tid; i < 2 * D16; i += 256) qs[i] = reinterpret_cast<const v4f*>(q)[i];
     // ||q|| with the reference's sequential sum (needed for cosine scores here, and
     // published once for the final stage's exact scoring and error bound)
-    if (wid == 0 && (METRIC == 0 || blockIdx.x == 0)) {
+    if (wid == 0 && (METRIC == 0 || track || blockIdx.x == 0)) {
         const float nsq = query_norm_sq_wave(q, D, lane);
         if (lane == 0) {
+            nsq_sh = nsq;
             na_sh = sqrtf(nsq);
             if (blockIdx.x == 0) publish_ctl(ctl, nsq, need, k, vmax_sq, gridDim.x * 4u);
         }
@@ -128,6 +133,18 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     const uint32_t n_waves = gridDim.x * 4u;
     const uint32_t last = n_rows - 1u;
+    // The select lowers its threshold to (k-th best bounded approximate score) - 2.02 eps; the
+    // keys kept reach a little further down, in the same arithmetic (0: no valid bound, keep all).
+    float keep_margin = -1.0f;
+    if (track) {
+        const float nsq = nsq_sh;
+        const float eps = mirror_eps<METRIC>(D, na_sh, sqrtf(*vmax_sq));
+        if ((nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f)) && eps < INFINITY) keep_margin = 2.02f * eps * 1.01f;
+    }
+    uint32_t keep_key = 0u;    // tiles whose best key is below this are not stored
+    uint32_t keep_best = 0u;   // best bounded key this wave has seen
+    uint32_t tiles_done = 0u;
+    unsigned long long polled[16];
 
     // Two groups of U row-iterations ping-pong through registers: the loads of the next
     // group (of this tile or of the wave's next tile) are in flight while the current one
@@ -165,6 +182,8 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
         const uint32_t row = row0 + (uint32_t)(sub * ITERS + gl);  // = row0 + lane
         float nb2 = 0.0f;
         if (METRIC == 0) nb2 = norm2[min(row, last)];
+        const bool poll = track && sparse_poll_at(tiles_done);
+        if (poll) sparse_poll_issue(wbest, lane, polled);   // (used after the tile: the latency hides behind it)
 #pragma unroll 1
         for (int it0 = 0; it0 < ITERS; it0 += 2 * U) {
             issue(xb, t, it0 + U);
@@ -195,9 +214,21 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
                 key = score_key(s);
                 atomicAdd(&lhist[key >> 21], 1u);
             }
-            keys[row] = key;
         }
         const uint32_t tm = wave_max_u32(key);
+        if (track) {
+            // (+inf marks rows without a valid bound: never one of the k bounded rows)
+            if (tm >= 0x007FFFFFu && tm < 0xFF800000u && tm > keep_best) keep_best = tm;
+            ++tiles_done;
+            if (sparse_publish_at(tiles_done) && lane == 0)
+                __hip_atomic_store(wbest + (blockIdx.x * 4u + wid), ((unsigned long long)epoch << 32) | keep_best,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (poll && keep_margin >= 0.0f) {
+                const uint32_t kk = sparse_keep_key(sparse_poll_value(polled, epoch, k), keep_margin);
+                keep_key = kk > keep_key ? kk : keep_key;
+            }
+        }
+        if (row < n_rows && tm >= keep_key) keys[row] = key;
         if (lane == 0) tmax[t] = tm;
         wave_best = tm > wave_best ? tm : wave_best;
     }
@@ -240,7 +271,8 @@ static uint32_t launch_one(const uint16_t* mirror, const float* d_q, const float
     }
     if (grid > cap) grid = cap;
     hipLaunchKernelGGL((scan_mirror_kernel<METRIC, G, NV, U>), dim3(grid), dim3(256), 0, st, mirror, d_q,
-                       d_norm2, a.dead, a.n_rows, need, k, d_vmax_sq, s.ctl, s.keys, s.tmax, s.wmax, s.hist);
+                       d_norm2, a.dead, a.n_rows, need, k, d_vmax_sq, s.ctl, s.keys, s.tmax, s.wmax, s.hist,
+                       s.wbest, sparse_scan_pays(n_tiles, grid * 4u) && s.wbest ? s.epoch : 0u);
     return grid * 4u;
 }
 

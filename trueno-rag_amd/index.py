@@ -295,7 +295,8 @@ class VectorStore:
         st = _abi.SearchStats()
         _abi.check(_abi.lib().trag_store_last_stats(self._h, C.byref(st)))
         return {"mode_used": st.mode_used, "candidates": st.candidates,
-                "refine_levels": st.refine_levels, "fallbacks": st.fallbacks}
+                "refine_levels": st.refine_levels, "fallbacks": st.fallbacks,
+                "keys_kept_from": st.keys_kept_from}
 
     @property
     def handle(self):
