@@ -76,6 +76,16 @@ def test_sparse_key_stores_change_nothing(trag, oracle, metric):
                             gathered[sparse, mode] = store.last_stats()["keys_kept_from"]
                         assert_same_ranking(rows, scores, er, es,
                                             f"sparse={sparse} mode={mode} metric={metric} query {qi} k={k}")
+            # alternating queries whose best rows sit in different tiles: each leaves keys in keys[]
+            # that would beat everything in the other's answer if a skipped tile were ever read
+            store.set_scan_mode(0)
+            picks = [5 * 64 + 1, 900_000, 2_222_222, N - 70]
+            for rep in range(3):
+                for r in picks:
+                    q = corpus[r] + np.float32(1e-3) * rng.standard_normal(D).astype(np.float32)
+                    rows, scores = store.search_rows(q, 10)
+                    er, es = oracle.search(corpus, q, 10, metric, dead=dead)
+                    assert_same_ranking(rows, scores, er, es, f"sparse={sparse} alternating row {r} metric={metric}")
             store.close()
         finally:
             os.environ.pop("TRAG_SPARSE_KEYS", None)
