@@ -22,7 +22,8 @@ constexpr uint32_t SPARSE_WAVES = 1024;
 // ... and the scans long enough for them to pay: the polls cost a wave ~2 us each and the first
 // tiles of every wave are stored regardless. MI355X, scan time with / without: exact 10M x 384
 // 2.262 / 2.382 ms, mirror 10M x 384 1.170 / 1.262; switched on for every size: 1M x 384 exact
-// 0.249 / 0.238, 1.25M x 384 0.303 / 0.295, 2M x 768 0.912 / 0.917, 2M x 4096 unchanged.
+// 0.249 / 0.238, 1.25M x 384 0.303 / 0.295, 2M x 768 0.912 / 0.917, 2M x 4096 unchanged (with
+// one polling wave per workgroup instead of all four: 0.245 / 0.240, 0.299 / 0.295, 0.909 / 0.918).
 inline bool sparse_scan_pays(uint32_t n_tiles, uint32_t n_waves) { return n_waves > 0 && n_tiles / n_waves >= 40u; }
 
 // Final status written per query.

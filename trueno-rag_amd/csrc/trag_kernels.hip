@@ -88,7 +88,9 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
     __shared__ __attribute__((aligned(16))) float tiles[WPB][64 * EX_STRIDE];
     __shared__ uint32_t lhist[HIST_BINS];
     __shared__ float na_sh;
+    __shared__ uint32_t keep_lds;   // sparse key stores: the bound wave 0 of the workgroup last computed
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) keep_lds = 0u;
     for (int i = tid; i < (int)HIST_BINS; i += WPB * 64) lhist[i] = 0u;
 
     float* tile = tiles[wid];
@@ -134,7 +136,7 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
         unsigned long long polled[16];
         while (t < n_tiles) {
             float acc0 = 0.0f, acc1 = 0.0f;
-            const bool poll = track && sparse_poll_at(tiles_done);
+            const bool poll = track && wid == 0 && sparse_poll_at(tiles_done);   // one poller per workgroup
             if (poll) sparse_poll_issue(wbest, lane, polled);   // (used after the tile)
             for (uint32_t c = 0; c < n_chunks; ++c) {
                 // Stage chunk c (the reads of the previous chunk are older DS ops of this wave) and
@@ -202,8 +204,12 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (poll) {
                     const uint32_t kk = sparse_poll_value(polled, epoch, need);
+                    if (kk > keep_key && lane == 0) __hip_atomic_store(&keep_lds, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     keep_key = kk > keep_key ? kk : keep_key;
                 }
+                // (the other waves pick the poller's bound up whenever it appears: any value it ever held is valid)
+                const uint32_t shared_kk = __hip_atomic_load(&keep_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                keep_key = shared_kk > keep_key ? shared_kk : keep_key;
             }
             if (row < n_rows && tm >= keep_key) keys[row] = key;
             if (lane == 0) {

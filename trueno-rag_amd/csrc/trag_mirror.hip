@@ -106,9 +106,11 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
     __shared__ v4f qs[2 * D16];
     __shared__ uint32_t lhist[HIST_BINS];
     __shared__ float na_sh, nsq_sh;
+    __shared__ uint32_t keep_lds;   // sparse key stores: the bound wave 0 of the workgroup last computed
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // sparse key stores (trag_scan_common.h): on when the launcher passes an epoch
     const bool track = epoch != 0u && k >= 1u && k <= 64u && gridDim.x * 4u <= SPARSE_WAVES;
+    if (tid == 0) keep_lds = 0u;
     for (int i = tid; i < (int)HIST_BINS; i += 256) lhist[i] = 0u;
     for (int i = tid; i < 2 * D16; i += 256) qs[i] = reinterpret_cast<const v4f*>(q)[i];
     // ||q|| with the reference's sequential sum (needed for cosine scores here, and
@@ -182,7 +184,7 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
         const uint32_t row = row0 + (uint32_t)(sub * ITERS + gl);  // = row0 + lane
         float nb2 = 0.0f;
         if (METRIC == 0) nb2 = norm2[min(row, last)];
-        const bool poll = track && sparse_poll_at(tiles_done);
+        const bool poll = track && wid == 0 && sparse_poll_at(tiles_done);   // one poller per workgroup
         if (poll) sparse_poll_issue(wbest, lane, polled);   // (used after the tile: the latency hides behind it)
 #pragma unroll 1
         for (int it0 = 0; it0 < ITERS; it0 += 2 * U) {
@@ -225,8 +227,12 @@ scan_mirror_kernel(const uint16_t* __restrict__ mirror, const float* __restrict_
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (poll && keep_margin >= 0.0f) {
                 const uint32_t kk = sparse_keep_key(sparse_poll_value(polled, epoch, k), keep_margin);
+                if (kk > keep_key && lane == 0) __hip_atomic_store(&keep_lds, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 keep_key = kk > keep_key ? kk : keep_key;
             }
+            // (the other waves pick the poller's bound up whenever it appears: any value it ever held is valid)
+            const uint32_t shared_kk = __hip_atomic_load(&keep_lds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            keep_key = shared_kk > keep_key ? shared_kk : keep_key;
         }
         if (row < n_rows && tm >= keep_key) keys[row] = key;
         if (lane == 0) tmax[t] = tm;

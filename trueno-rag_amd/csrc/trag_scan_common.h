@@ -64,8 +64,9 @@ __device__ __forceinline__ void publish_ctl(SearchCtl* __restrict__ ctl, float n
 //
 // The bound: every wave publishes the best (bounded) key it has seen so far in wbest[wave],
 // tagged with the scan's epoch, after its 1st, 4th, 16th and 64th tile; at the start of its
-// 3rd, 9th, 33rd and 129th tile it reads all entries and takes their count-th largest value
-// V. The entries are keys of distinct rows, so at least `count` rows have a key >= V, the
+// 3rd, 9th, 33rd and 129th tile the first wave of each workgroup reads all entries (the loads
+// are issued there and used when the tile is done), takes their count-th largest value V and
+// leaves the bound in LDS for the workgroup's other waves. The entries are keys of distinct rows, so at least `count` rows have a key >= V, the
 // count-th best key of the corpus is >= V, and no stage needs a row below V (lowered by the
 // metric-space margin where the select lowers its threshold): tiles whose maximum is below
 // that need no keys. Entries only grow, so the value computed from the entries left at the
