@@ -66,10 +66,10 @@ __device__ __forceinline__ void publish_ctl(SearchCtl* __restrict__ ctl, float n
 // tagged with the scan's epoch, after its 1st, 4th, 16th and 64th tile; at the start of its
 // 3rd, 9th, 33rd and 129th tile the first wave of each workgroup reads all entries (the loads
 // are issued there and used when the tile is done), takes their count-th largest value V and
-// leaves the bound in LDS for the workgroup's other waves. The entries are keys of distinct rows, so at least `count` rows have a key >= V, the
-// count-th best key of the corpus is >= V, and no stage needs a row below V (lowered by the
-// metric-space margin where the select lowers its threshold): tiles whose maximum is below
-// that need no keys. Entries only grow, so the value computed from the entries left at the
+// leaves the bound in LDS for the workgroup's other waves. The entries are keys of distinct
+// rows, so at least `count` rows have a key >= V, the count-th best key of the corpus is >= V,
+// and no stage needs a row below V (lowered by the metric-space margin where the select lowers
+// its threshold): tiles whose maximum is below that need no keys. Entries only grow, so the value computed from the entries left at the
 // end of the scan is >= every value a wave used: the select computes it with the same
 // function and raises its cut to it, and thereby never visits a tile that was skipped.
 // Entries of other epochs read as 0 (nothing is ever reset).
