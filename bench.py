@@ -265,6 +265,13 @@ def main():
         # the exact-order scan of the same query must return the same rows and score bits
         store.set_scan_mode(1)
         er, es = store.search_rows(Q[-1].cpu().numpy(), k)
+        # (long single-query scans skip the key stores no later stage reads; nonzero = the bound in force)
+        parity["exact_scan_keys_kept_from"] = int(store.last_stats()["keys_kept_from"])
+        # ... and an independent route over the full corpus: the streaming scan (another kernel, every
+        # key stored, candidates re-scored in the reference's order) must agree bit for bit as well
+        store.set_scan_mode(2)
+        sr, ss = store.search_rows(Q[-1].cpu().numpy(), k)
+        parity["streaming_scan_identical"] = bool(np.array_equal(sr, er) and ss.tobytes() == es.tobytes())
         store.set_scan_mode(args.mode)
         parity["exact_scan_identical"] = bool(np.array_equal(er, final_rows) and es.tobytes() == final_scores.tobytes())
 
