@@ -86,6 +86,18 @@ def test_sparse_key_stores_change_nothing(trag, oracle, metric):
                     rows, scores = store.search_rows(q, 10)
                     er, es = oracle.search(corpus, q, 10, metric, dead=dead)
                     assert_same_ranking(rows, scores, er, es, f"sparse={sparse} alternating row {r} metric={metric}")
+            # TRAG_SPARSE_HUNT=n: n more random queries per scan (bug hunts; off by default)
+            hunt = np.random.default_rng(4242 + metric)
+            for i in range(int(os.environ.get("TRAG_SPARSE_HUNT", "0"))):
+                q = hunt.standard_normal(D).astype(np.float32)
+                if i % 5 == 0:
+                    q = corpus[int(hunt.integers(N))] + np.float32(0.05) * q
+                kk = int(hunt.choice([1, 5, 10, 33, 64]))
+                er, es = oracle.search(corpus, q, kk, metric, dead=dead)
+                for mode in (EXACT, MIRROR):
+                    store.set_scan_mode(mode)
+                    rows, scores = store.search_rows(q, kk)
+                    assert_same_ranking(rows, scores, er, es, f"hunt {i} sparse={sparse} mode={mode} metric={metric} k={kk}")
             store.close()
         finally:
             os.environ.pop("TRAG_SPARSE_KEYS", None)
