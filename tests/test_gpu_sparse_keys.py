@@ -1,4 +1,4 @@
-"""GPU: scans long enough to skip the key stores of tiles no later stage can read (40 or more
+"""GPU: scans long enough to skip the key stores of tiles no later stage can read (28 or more
 tiles per scan wave: 2.7 M rows here) must return exactly what they return with every key
 stored, and what the oracle returns. The corpora put the best rows where the bound is weakest:
 all in the tiles of one scan wave, all in a wave's first or last tiles, in tie groups that

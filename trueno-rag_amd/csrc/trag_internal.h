@@ -24,7 +24,9 @@ constexpr uint32_t SPARSE_WAVES = 1024;
 // 2.262 / 2.382 ms, mirror 10M x 384 1.170 / 1.262; switched on for every size: 1M x 384 exact
 // 0.249 / 0.238, 1.25M x 384 0.303 / 0.295, 2M x 768 0.912 / 0.917, 2M x 4096 unchanged (with
 // one polling wave per workgroup instead of all four: 0.245 / 0.240, 0.299 / 0.295, 0.909 / 0.918).
-inline bool sparse_scan_pays(uint32_t n_tiles, uint32_t n_waves) { return n_waves > 0 && n_tiles / n_waves >= 40u; }
+// Exact scan at 384 dimensions by rows, with / without: 2M 0.460 / 0.466, 2.5M 0.575 / 0.582, 3.3M 0.745 / 0.766:
+// on from 28 tiles per wave.
+inline bool sparse_scan_pays(uint32_t n_tiles, uint32_t n_waves) { return n_waves > 0 && n_tiles / n_waves >= 28u; }
 
 // Final status written per query.
 constexpr uint32_t ST_OK = 0;
