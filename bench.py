@@ -69,11 +69,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started as plain `python bench.py --gpus N`: launch the N ranks (one process per GPU) as
+        # children of this process, which has not touched the GPU, and hand their exit code on
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world != args.gpus and rank == 0:
+        print(f"--gpus {args.gpus} but WORLD_SIZE={world}: running with {world} rank(s)", file=sys.stderr)
     import torch.distributed as dist
     # HBM traffic of the scan kernel from the hardware counters: a short copy of this very run
     # under rocprofv3, started before this process touches the GPU
@@ -94,10 +103,10 @@ def main():
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # torch.distributed is the control plane only (rendezvous, barrier, the max over ranks of
+        # the elapsed time: host memory over gloo); the data-path collective -- the all-gather of the
+        # per-shard top-k lists -- is RCCL inside libtrag.so (trag_shard_search_device)
+        dist.init_process_group("gloo")
     pkg = load_package()
     L = pkg.lib()
 
@@ -131,17 +140,22 @@ def main():
     stream = torch.cuda.current_stream()
     sptr = stream.cuda_stream
     esz = 4
-    ex = None
+    ex = None      # rehearsal only: the Python exchange over gloo (several ranks on one GPU)
+    group = None   # the real thing: one C call per step, RCCL inside the library
     # TRAG_BENCH_FORCE_EXCHANGE=1 runs the pack / gather / merge leg on one GPU too (world size 1)
     if world > 1 or os.environ.get("TRAG_BENCH_FORCE_EXCHANGE"):
-        from trueno_rag_amd.sharded import ShardExchange
-        ex = ShardExchange(k, max_queries=B, device=torch.device("cuda", local))
+        from trueno_rag_amd.sharded import ShardExchange, ShardGroup
+        BX = max(B, 1000)   # the second leg of an N > 1 run sends 1000 queries per step through the exchange
+        if one_gpu:
+            ex = ShardExchange(k, max_queries=BX, device=torch.device("cuda", local))
+            side = torch.cuda.Stream()
+        else:
+            # overlap: pack / all-gather / merge of step i run on the library's exchange stream while
+            # the scan of step i+1 runs on ours; group.fence() before the results are consumed
+            group = ShardGroup(rank, world, local, k_max=k, max_queries=BX, overlap=True)
         m_rows = torch.zeros((n_q, k), dtype=torch.int32, device="cuda")
         m_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
         m_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
-        # the exchange of step i runs on a side stream while the scan of step i+1 runs on the
-        # main one (the merged results are only consumed after the final synchronize)
-        side = torch.cuda.Stream()
 
     hybrid_out = []
     sparse_info = None
@@ -186,6 +200,11 @@ def main():
         if args.host:   # PCIe and the synchronisation are inside the step here, by definition of this mode
             host_out["rows"], host_out["scores"], _ = store.search_batch_rows(Q_host[i:i + B], k)
             return
+        if group is not None:   # local scan -> records -> ONE RCCL all-gather -> merge: one C call
+            group.search_device(store, row0, 1, Q.data_ptr() + i * d * esz, B, k, m_rows.data_ptr() + i * k * esz,
+                                m_scores.data_ptr() + i * k * esz, m_n.data_ptr() + i * esz,
+                                status.data_ptr() + i * esz, sptr)
+            return
         store.search_device(Q.data_ptr() + i * d * esz, B, k, out_rows.data_ptr() + i * k * esz,
                             out_scores.data_ptr() + i * k * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
@@ -198,6 +217,8 @@ def main():
                             m_rows[i:i + B], m_scores[i:i + B], m_n[i:i + B], side.cuda_stream)
 
     def fence():
+        if group is not None:
+            group.fence(sptr)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -233,35 +254,47 @@ def main():
     store.set_profiling(False)
     mode_used = store.last_stats()["mode_used"]  # the path the timed steps actually took
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    batch_leg = None
+    if (group is not None or ex is not None) and not args.hybrid and B != 1000:
+        batch_leg = exchange_batch_leg(args, store, group, ex, side if ex is not None else None, rank, world, row0,
+                                       d, k, seed, sptr, stream, fence, dist)
 
     # ---- parity at full size (outside the timed region) ----
     uncertified = int((status[args.warmup * B:] != 0).sum().item())
     if args.hybrid:
         out_rows, out_scores = h_rows, h_scores
         k = cand
-    final_rows = (m_rows if ex is not None else out_rows)[-1].cpu().numpy().astype(np.uint32)
-    final_scores = (m_scores if ex is not None else out_scores)[-1].cpu().numpy()
+    sharded = ex is not None or group is not None
+    if group is not None:   # the local list of the last query, for the host-side check of the merge
+        store.search_device(Q.data_ptr() + (n_q - 1) * d * esz, 1, k, out_rows.data_ptr() + (n_q - 1) * k * esz,
+                            out_scores.data_ptr() + (n_q - 1) * k * esz, out_n.data_ptr() + (n_q - 1) * esz, 0, sptr)
+        torch.cuda.synchronize()
+    final_rows = (m_rows if sharded else out_rows)[-1].cpu().numpy().astype(np.uint32)
+    final_scores = (m_scores if sharded else out_scores)[-1].cpu().numpy()
     if args.host:
         final_rows, final_scores = host_out["rows"][-1].astype(np.uint32), host_out["scores"][-1]
         uncertified = 0   # the host entry repeats unfinished queries itself
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
-    if world > 1:
+    if world > 1 or sharded:
         # the device merge of the last query against a host merge of every rank's own list
         # (descending score, ascending global row; gathered as plain Python objects)
         mine = (out_rows[-1].cpu().numpy().astype(np.int64) + row0, out_scores[-1].cpu().numpy(),
                 int(out_n[-1].item()))
         lists = [None] * world
-        dist.all_gather_object(lists, mine)
+        if world > 1:
+            dist.all_gather_object(lists, mine)
+        else:
+            lists = [mine]
         g_rows = np.concatenate([r[:n] for r, _, n in lists])
         g_scores = np.concatenate([sc[:n] for _, sc, n in lists])
         order = np.lexsort((g_rows, -g_scores.astype(np.float64)))[:k]
         parity["device_merge_equals_host_merge"] = bool(
             np.array_equal(g_rows[order], final_rows.astype(np.int64)[:len(order)])
             and g_scores[order].tobytes() == final_scores[:len(order)].tobytes())
-    if world == 1:
+    if world == 1 and not sharded:
         # the exact-order scan of the same query must return the same rows and score bits
         store.set_scan_mode(1)
         er, es = store.search_rows(Q[-1].cpu().numpy(), k)
@@ -316,6 +349,10 @@ def main():
                        f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, {args.metric} top-{k}",
                        "rows": n_total, "dim": d, "k": k, "batch": B, "metric": args.metric,
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
+                       "exchange": ("one trag_shard_search_device call per step: local scan, records, RCCL "
+                                    "all-gather (version %d), merge on every rank; exchange of step i overlaps "
+                                    "the scan of step i+1" % rccl_version_or_zero()) if group is not None else
+                                   ("Python ShardExchange over gloo (rehearsal)" if ex is not None else None),
                        "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma", 4: "bf16-prefilter", 5: "bf16-mirror"}[args.mode],
                        "bf16_mirror": bool(args.mirror),
                        "entry": "host pointers (PCIe + synchronisation inside every step)" if args.host
@@ -340,6 +377,8 @@ def main():
                 bm25.search_ids(q_terms[i % len(q_terms)], cand)
             sparse_info["search_ms_alone"] = 1e3 * (time.perf_counter() - t0) / 20
             result["config"]["sparse"] = sparse_info
+        if batch_leg is not None:
+            result["batch_1000"] = batch_leg
         if traffic is not None:
             result["roofline"]["traffic"] = traffic.pop("bytes_per_launch")
             result["roofline"]["traffic_source"] = traffic
@@ -360,9 +399,76 @@ def main():
             result["cpu_baseline"] = cpu_baseline(store, Q, n_local, n_total, d, k, args.cpu_sample_rows,
                                                   seed, row0, metric_id)
         print(json.dumps(result), flush=True)
+    if group is not None:
+        group.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rccl_version_or_zero():
+    try:
+        from trueno_rag_amd.sharded import rccl_version
+        return rccl_version()
+    except Exception:  # noqa: BLE001
+        return 0
+
+
+def exchange_batch_leg(args, store, group, ex, side, rank, world, row0, d, k, seed, sptr, stream, fence, dist):
+    """Second leg of a sharded run: 1000 queries per step (BASELINE config 4's batch) through the
+    same local search -> all-gather -> merge step. Reported beside the headline leg."""
+    BX = 1000
+    steps, warm = max(2, min(args.steps, 10)), 1
+    n_q = (steps + warm) * BX
+    Q = torch.from_numpy(unit_queries(n_q, d, seed + 200)).cuda()
+    rows = torch.zeros((n_q, k), dtype=torch.int32, device="cuda")
+    scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+    status = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+    if ex is not None:
+        l_rows, l_scores, l_cnt = torch.zeros_like(rows), torch.zeros_like(scores), torch.zeros_like(cnt)
+
+    def step(s):
+        i = s * BX
+        if group is not None:
+            group.search_device(store, row0, 1, Q.data_ptr() + i * d * 4, BX, k, rows.data_ptr() + i * k * 4,
+                                scores.data_ptr() + i * k * 4, cnt.data_ptr() + i * 4, status.data_ptr() + i * 4, sptr)
+            return
+        store.search_device(Q.data_ptr() + i * d * 4, BX, k, l_rows.data_ptr() + i * k * 4,
+                            l_scores.data_ptr() + i * k * 4, l_cnt.data_ptr() + i * 4, status.data_ptr() + i * 4, sptr)
+        done = torch.cuda.Event()
+        done.record(stream)
+        side.wait_event(done)
+        with torch.cuda.stream(side):
+            ex.exchange(l_rows[i:i + BX], l_scores[i:i + BX], l_cnt[i:i + BX], row0, rows[i:i + BX], scores[i:i + BX],
+                        cnt[i:i + BX], side.cuda_stream)
+
+    for s in range(warm):
+        step(s)
+    fence()
+    t0 = time.perf_counter()
+    for s in range(warm, warm + steps):
+        step(s)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    unfinished = int((status[warm * BX:] != 0).sum().item())
+    # every rank must hold the same merged lists: compare a checksum of this rank's with rank 0's
+    digest = [int(rows[warm * BX:].to(torch.int64).sum().item()), int(cnt.sum().item()),
+              float(scores[warm * BX:].double().sum().item())]
+    same = True
+    if world > 1:
+        all_d = [None] * world
+        dist.all_gather_object(all_d, digest)
+        same = all(x == all_d[0] for x in all_d)
+    sc = scores[-1].cpu().numpy()
+    return {"value": steps * BX / elapsed, "unit": "queries/s", "batch": BX, "steps": steps,
+            "ms_per_step": 1e3 * elapsed / steps, "unfinished_queries": unfinished,
+            "sorted": bool(np.all(sc[:-1] >= sc[1:])), "all_ranks_hold_the_same_lists": bool(same),
+            "path_used": store.last_stats()["mode_used"]}
 
 
 def mirror_leg(store, args, Q, out_rows, out_scores, out_n, status, n_local, d, B, k, esz, sptr):

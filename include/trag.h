@@ -19,9 +19,15 @@
  *    ascending row index; NaN scores come last.
  *  - Return value 0 = OK; the message of the last failure on the calling
  *    thread is available from trag_last_error().
- *  - Thread contract mirrors &self / &mut self: searches on one handle may run
- *    concurrently (they serialise on an internal lock); insert/overwrite/
- *    remove/reserve need exclusive access.
+ *  - Thread contract mirrors &self / &mut self: searches on one handle may be
+ *    issued concurrently; insert/overwrite/remove/reserve need exclusive access.
+ *    A handle owns ONE search scratch, so its searches run one after the other:
+ *    the host-pointer entries hold an internal lock until their results are
+ *    back; the `_device` entries hold it while they enqueue, and a call that
+ *    arrives on another stream than the handle's previous call (a caller's
+ *    stream, then the handle's own, or two caller streams) first makes the new
+ *    stream wait for the work the previous call enqueued. A stream passed to a
+ *    `_device` entry must stay alive until the handle's next call.
  */
 #ifndef TRAG_H
 #define TRAG_H
@@ -188,13 +194,101 @@ trag_status trag_merge_topk_device(const uint32_t *d_rows, const float *d_scores
  * n_queries such records from a search result (adding first_global_row to the
  * local row ids); after an all-gather the receive buffer holds
  * [n_lists][n_queries][2k+1] words and trag_merge_packed_device reduces it to
- * the global top-k per query (same ordering rule as search). n_lists * k <= 4096. */
+ * the global top-k per query (same ordering rule as search). n_lists * k <= 4096. Bits 16..23 of
+ * a record's count word may carry the status of that query on that shard (0 = final); the merge
+ * ignores them here (trag_shard_search_device reports them). */
 trag_status trag_pack_topk_device(const uint32_t *d_rows, const float *d_scores, const uint32_t *d_n,
                                   uint32_t first_global_row, uint32_t n_queries, uint32_t k,
                                   uint32_t *d_packed, void *hip_stream);
 trag_status trag_merge_packed_device(const uint32_t *d_gathered, uint32_t n_lists,
                                      uint32_t n_queries, uint32_t k, uint32_t *d_out_rows,
                                      float *d_out_scores, uint32_t *d_out_n, void *hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Sharded search: the corpus partitioned by rows over the GPUs of one node.
+ * No counterpart in the reference (single process, one thread); the call this
+ * serves is the dense search of HybridRetriever::retrieve (src/retrieve.rs:181)
+ * and of DenseRetriever::retrieve (:286) when one GPU's HBM or bandwidth is
+ * not enough. Every shard answers the query batch from its own rows, ONE
+ * all-gather (RCCL over xGMI) moves the per-shard lists in the wire format
+ * above, and every GPU merges them with the ordering rule of a single store.
+ * RCCL is looked up at run time (dlopen of librccl.so.1; TRAG_RCCL_LIB names
+ * another file): the process decides which copy it runs.
+ * ------------------------------------------------------------------------ */
+
+/* (a) One rank per process (one GPU each), the launch model of
+ * torch.distributed / MPI. Rank 0 makes an id, the host program carries its
+ * TRAG_SHARD_ID_BYTES bytes to the other ranks, every rank creates its group
+ * (a collective call: ncclCommInitRank). */
+#define TRAG_SHARD_ID_BYTES 128
+typedef struct trag_shard_group trag_shard_group;
+typedef struct trag_shard_config {
+    uint32_t rank, world;
+    int32_t device;       /* HIP device ordinal of this rank; -1 = current device */
+    uint32_t k_max;       /* largest k of later searches; world * k_max <= 4096 */
+    uint32_t max_queries; /* largest batch of one trag_shard_search_device call */
+    uint32_t overlap;     /* 0: pack, all-gather and merge follow the local search on the caller's
+                             stream. 1: they run on the group's own stream, so the next call's scan
+                             overlaps this call's exchange; results are visible to a stream only
+                             after trag_shard_fence on it. */
+} trag_shard_config;
+trag_status trag_shard_unique_id(uint8_t *id /* TRAG_SHARD_ID_BYTES */);
+trag_status trag_shard_group_create(const trag_shard_config *cfg, const uint8_t *id, trag_shard_group **out);
+void trag_shard_group_destroy(trag_shard_group *g);
+
+/* Collective: every rank calls it with the same queries, n_queries and k. `local` is this rank's
+ * shard; its local row r is global row row0 + r * row_mul (contiguous shards: row0 = first global
+ * row, row_mul = 1; shards striped over the ranks: row0 = rank, row_mul = world). One call
+ * enqueues local search -> records -> all-gather -> merge; every rank receives the global top k
+ * (global row ids) in its own d_out_* arrays. d_status[b] (optional) is the worst status any
+ * shard reported for query b (codes of trag_store_search_device): non-zero asks for
+ * trag_shard_search_batch. Device pointers, no synchronisation. */
+trag_status trag_shard_search_device(trag_shard_group *g, trag_store *local, uint32_t row0, uint32_t row_mul,
+                                     const float *d_queries, uint32_t n_queries, uint32_t dim, uint32_t k,
+                                     uint32_t *d_out_rows, float *d_out_scores, uint32_t *d_out_n,
+                                     uint32_t *d_status, void *hip_stream);
+/* Makes hip_stream wait for every exchange enqueued so far (needed with overlap = 1). */
+trag_status trag_shard_fence(trag_shard_group *g, void *hip_stream);
+/* Host pointers, synchronous, any n_queries; finishes every query (the shard's host entry
+ * repeats what its fast path gave up). Collective as well. */
+trag_status trag_shard_search_batch(trag_shard_group *g, trag_store *local, uint32_t row0, uint32_t row_mul,
+                                    const float *queries, uint32_t n_queries, uint32_t dim, uint32_t k,
+                                    uint32_t *out_rows, float *out_scores, uint32_t *out_n);
+/* NCCL-style version code of the RCCL in use (e.g. 22707). */
+trag_status trag_shard_rccl_version(int *version);
+
+/* (b) One process, n GPUs: a VectorStore striped over device_ids[0..n_devices) -- global row g
+ * lives on shard g % n as local row g / n, so appends keep the shards level, global row ids
+ * never move and ascending global row stays insertion order (the tie rule carries over). One
+ * communicator over all devices (ncclCommInitAll), one stream per GPU. cfg->device is ignored,
+ * cfg->reserve_rows is the whole store's. The method surface is VectorStore's
+ * (src/index.rs:335-437), as trag_store_*. */
+typedef struct trag_sharded_store trag_sharded_store;
+typedef enum trag_exchange {
+    TRAG_EXCHANGE_RCCL = 0, /* queries by ncclBroadcast, records by ncclAllGather */
+    TRAG_EXCHANGE_COPY = 1  /* the same exchange as device-to-device copies ordered by events: for
+                               boxes without RCCL and for device lists RCCL refuses (the same GPU
+                               named twice, which is how the n > 1 logic is tested on one GPU) */
+} trag_exchange;
+trag_status trag_sharded_create(const trag_config *cfg, uint32_t n_devices, const int32_t *device_ids,
+                                uint32_t exchange, trag_sharded_store **out);
+void trag_sharded_destroy(trag_sharded_store *s);
+trag_status trag_sharded_insert(trag_sharded_store *s, const float *rows, uint64_t n, uint32_t dim,
+                                uint32_t *out_first_row);
+trag_status trag_sharded_overwrite(trag_sharded_store *s, uint32_t row, const float *vec, uint32_t dim);
+trag_status trag_sharded_remove(trag_sharded_store *s, uint32_t row);
+uint64_t trag_sharded_len(const trag_sharded_store *s);
+uint64_t trag_sharded_rows(const trag_sharded_store *s);
+trag_status trag_sharded_search(trag_sharded_store *s, const float *query, uint32_t dim, uint32_t k,
+                                uint32_t *out_rows, float *out_scores, uint32_t *out_n);
+trag_status trag_sharded_search_batch(trag_sharded_store *s, const float *queries, uint32_t n_queries,
+                                      uint32_t dim, uint32_t k, uint32_t *out_rows, float *out_scores,
+                                      uint32_t *out_n);
+/* Global rows [first, first + n) of the library's synthetic generator (trag_store_fill_synthetic). */
+trag_status trag_sharded_fill_synthetic(trag_sharded_store *s, uint64_t n, uint64_t seed, uint32_t *out_first_row);
+uint32_t trag_sharded_devices(const trag_sharded_store *s);
+/* Shard i's store, for per-shard settings (scan mode, bf16 mirror, statistics). Not for insert. */
+trag_store *trag_sharded_shard(trag_sharded_store *s, uint32_t i);
 
 /* Optional bf16 copy of the corpus in HBM (1.5 x the memory, dimension % 8 == 0),
  * kept in step with insert / overwrite / fill. It halves the bytes a prefiltering

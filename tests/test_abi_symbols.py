@@ -41,3 +41,35 @@ def test_no_gpu_is_reported_not_faked(trag):
         assert e.status == 3 and "no HIP device" in str(e)
     else:
         raise AssertionError("store creation succeeded without a GPU")
+
+
+def test_sharded_entries_without_gpu_fail_loudly(trag):
+    """The sharded entry points resolve RCCL at run time and, like the store, have no CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    from trueno_rag_amd import sharded
+    assert sharded.rccl_version() >= 20000          # librccl was found and answers
+    for make in (lambda: sharded.MultiGpuVectorStore(trag.VectorStoreConfig(dimension=4), [0], "copy"),
+                 lambda: sharded.ShardGroup(0, 1, 0, 10)):
+        try:
+            make()
+        except trag.TragError as e:
+            assert e.status == 3 and "no HIP device" in str(e)
+        else:
+            raise AssertionError("a sharded object was created without a GPU")
+
+
+def test_fuse_errors_carry_their_own_message(trag):
+    """Every failing host entry sets the thread's last error (no stale message of an earlier call)."""
+    import ctypes as C
+    L = trag.lib()
+    n = C.c_uint32(7)
+    ids = (C.c_uint64 * 2)(1, 2)
+    out_ids, out_sc = (C.c_uint64 * 4)(), (C.c_float * 4)()
+    assert L.trag_fuse(9, 60.0, ids, None, 2, ids, None, 2, out_ids, out_sc, C.byref(n)) == 5
+    assert b"unknown strategy" in L.trag_last_error() and n.value == 0
+    assert L.trag_fuse(1, 0.5, ids, None, 2, ids, None, 2, out_ids, out_sc, C.byref(n)) == 5
+    assert b"scores" in L.trag_last_error()
+    assert L.trag_merge_topk(None, None, None, 2, 3, 3, None, None, C.byref(n)) == 5
+    assert b"trag_merge_topk" in L.trag_last_error()

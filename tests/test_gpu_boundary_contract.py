@@ -1,0 +1,151 @@
+"""Contract of the C ABI around the search itself: calls on different streams against one handle,
+any k, ingestion one chunk at a time (the shape of HybridRetriever::index, src/retrieve.rs:156-164)."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from util import assert_same_ranking
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a GPU")]
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_device_entry_on_a_user_stream_then_host_entry(trag, oracle, mode):
+    """A handle has one scratch. A device-entry search enqueued on the caller's stream and a
+    host-entry search issued right behind it (the handle's own stream) must not overlap on the
+    GPU: both results equal the oracle's."""
+    import torch
+    n, d, k = 3_000_000, 64, 10      # a scan long enough (~0.15 ms) to still be running when the second call starts
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0, scan_mode=mode, reserve_rows=n))
+    store.fill_synthetic(n, 71)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(72, 0, 8, d)
+    dq = torch.from_numpy(Q).cuda()
+    user = torch.cuda.Stream()
+    other = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(4):
+        a, b, c = Q[2 * rep % 8], Q[(2 * rep + 1) % 8], Q[(2 * rep + 3) % 8]
+        rows = torch.zeros((2, k), dtype=torch.int32, device="cuda")
+        scores = torch.zeros((2, k), dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+        status = torch.full((2,), 9, dtype=torch.int32, device="cuda")
+        ia, ic = 2 * rep % 8, (2 * rep + 3) % 8
+        store.search_device(dq.data_ptr() + ia * d * 4, 1, k, rows.data_ptr(), scores.data_ptr(), cnt.data_ptr(),
+                            status.data_ptr(), user.cuda_stream)
+        hr, hs = store.search_rows(b, k)                      # host entry, at once
+        store.search_device(dq.data_ptr() + ic * d * 4, 1, k, rows.data_ptr() + k * 4, scores.data_ptr() + k * 4,
+                            cnt.data_ptr() + 4, status.data_ptr() + 4, other.cuda_stream)   # a second user stream
+        torch.cuda.synchronize()
+        assert status.cpu().tolist() == [0, 0]
+        for got_r, got_s, q in ((rows[0].cpu().numpy(), scores[0].cpu().numpy(), a), (hr, hs, b),
+                                (rows[1].cpu().numpy(), scores[1].cpu().numpy(), c)):
+            er, es = oracle.search(corpus, q, k, 0)
+            assert_same_ranking(got_r.astype(np.uint32), got_s, er, es, f"mode {mode} rep {rep}")
+    store.close()
+
+
+def test_bm25_device_entry_then_host_entry(trag):
+    """The same for the sparse index (one accumulator array per handle)."""
+    import torch
+    bm = trag.BM25Index(device=0)
+    bm.fill_synthetic(400_000, 5000, 32, 9)
+    ref = [bm.search_ids([3, 40, 7, 900], 10), bm.search_ids([1, 2, 3, 4, 5], 10)]
+    user = torch.cuda.Stream()
+    import ctypes as C
+    from trueno_rag_amd import _abi
+    for rep in range(4):
+        docs = torch.zeros(10, dtype=torch.int32, device="cuda")
+        scores = torch.zeros(10, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        status = torch.full((1,), 9, dtype=torch.int32, device="cuda")
+        q = np.array([3, 40, 7, 900], dtype=np.uint32)
+        _abi.check(trag.lib().trag_bm25_search_device(bm.handle, q.ctypes.data_as(C.POINTER(C.c_uint32)), 4, 10,
+                                                      C.c_void_p(docs.data_ptr()), C.c_void_p(scores.data_ptr()),
+                                                      C.c_void_p(cnt.data_ptr()), C.c_void_p(status.data_ptr()),
+                                                      C.c_void_p(user.cuda_stream)))
+        h_docs, h_scores = bm.search_ids([1, 2, 3, 4, 5], 10)
+        torch.cuda.synchronize()
+        if int(status.item()) == 0:     # (3 = this query wants the multi-level select: the host entry's business)
+            assert docs.cpu().numpy().astype(np.uint32).tolist() == ref[0][0].tolist()
+            assert scores.cpu().numpy().tobytes() == ref[0][1].tobytes()
+        assert h_docs.tolist() == ref[1][0].tolist() and h_scores.tobytes() == ref[1][1].tobytes()
+    bm.close()
+
+
+def test_any_k_is_legal(trag, oracle):
+    """The reference truncates to k (src/index.rs:409): 'give me everything' is a huge k."""
+    import ctypes as C
+    d = 8
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0))
+    rows = oracle.synth_rows(3, 0, 3, d)
+    store.insert_rows(rows)
+    q = oracle.synth_rows(4, 0, 1, d)[0]
+    r, s = store.search_rows(q, 2 ** 31)
+    er, es = oracle.search(rows, q, 3, 0)
+    assert_same_ranking(r, s, er, es, "k = 2^31, three rows")
+    # straight through the C ABI with arrays of 3 entries and a stride the library must not use up
+    out_r = (C.c_uint32 * 3)()
+    out_s = (C.c_float * 3)()
+    n = C.c_uint32()
+    qq = np.ascontiguousarray(q)
+    rc = trag.lib().trag_store_search(store.handle, qq.ctypes.data_as(C.POINTER(C.c_float)), d, 0xFFFFFFFF, out_r,
+                                      out_s, C.byref(n))
+    assert rc == 0 and n.value == 3 and list(out_r) == er.tolist()
+    bm = trag.BM25Index(device=0)
+    bm.add_token_ids(np.array([1, 2, 3, 1, 2, 1], dtype=np.uint32), np.array([0, 3, 5, 6], dtype=np.uint64))
+    docs, sc = bm.search_ids([1], 2 ** 31)
+    assert sorted(docs.tolist()) == [0, 1, 2]
+    store.close()
+    bm.close()
+
+
+def test_chunk_by_chunk_ingest_does_not_wait_for_the_gpu(trag, oracle):
+    """100 000 single-row inserts (the retrievers' index() loop): staged through pinned memory,
+    no synchronisation per call; the rows' norms are brought up to date before the next search."""
+    import ctypes as C
+    n, d, k = 100_000, 64, 10
+    rows = oracle.synth_rows(55, 0, n, d)
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0))
+    L, h = trag.lib(), store.handle
+    fp = C.POINTER(C.c_float)
+    first = C.c_uint32()
+    base = rows.ctypes.data
+    t0 = time.perf_counter()
+    for i in range(n):
+        rc = L.trag_store_insert(h, C.cast(base + i * d * 4, fp), 1, d, C.byref(first))
+        if rc != 0 or first.value != i:
+            raise AssertionError((i, rc, first.value))
+    elapsed = time.perf_counter() - t0
+    assert store.len() == n
+    Q = oracle.synth_rows(56, 0, 20, d)
+    for mode in (0, 1, 2):
+        store.set_scan_mode(mode)
+        for b in range(3):
+            r, s = store.search_rows(Q[b], k)
+            er, es = oracle.search(rows, Q[b], k, 0)
+            assert_same_ranking(r, s, er, es, f"after single-row ingest, mode {mode}")
+    store.set_scan_mode(0)
+    rb, sb, nb = store.search_batch_rows(Q, k)       # the matrix-core route reads the cached norms
+    for b in range(20):
+        er, es = oracle.search(rows, Q[b], k, 0)
+        assert_same_ranking(rb[b], sb[b], er, es, f"batch after single-row ingest, query {b}")
+    assert np.array_equal(store.read_rows(n - 5, 5), rows[-5:])
+    # interleaved with searches, a mirror and a removal
+    store.set_bf16_mirror(True)
+    extra = oracle.synth_rows(57, 0, 300, d)
+    for i in range(300):
+        store.insert_rows(extra[i:i + 1])
+        if i % 100 == 50:
+            store.remove_row(n + i - 1)
+    allrows = np.concatenate([rows, extra])
+    dead = np.zeros(n + 300, np.uint8)
+    dead[[n + 49, n + 149, n + 249]] = 1
+    for b in range(3):
+        r, s = store.search_rows(extra[b * 7], k)
+        er, es = oracle.search(allrows, extra[b * 7], k, 0, dead=dead)
+        assert_same_ranking(r, s, er, es, "mirror scan after interleaved ingest")
+    store.close()
+    assert elapsed < 2.0, f"100k single-row inserts took {elapsed:.2f} s"

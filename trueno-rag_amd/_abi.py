@@ -41,6 +41,14 @@ class BM25Config(C.Structure):
     _fields_ = [("k1", C.c_float), ("b", C.c_float), ("device", C.c_int32)]
 
 
+class ShardConfig(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("device", C.c_int32), ("k_max", C.c_uint32),
+                ("max_queries", C.c_uint32), ("overlap", C.c_uint32)]
+
+
+SHARD_ID_BYTES = 128
+
+
 class SearchStats(C.Structure):
     _fields_ = [("mode_used", C.c_uint32), ("candidates", C.c_uint32),
                 ("refine_levels", C.c_uint32), ("fallbacks", C.c_uint32), ("keys_kept_from", C.c_uint32)]
@@ -64,6 +72,28 @@ SIGNATURES = {
     "trag_store_search_device": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trag_store_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.c_uint64, _u32p]),
+    "trag_shard_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "trag_shard_group_create": (C.c_int, [C.POINTER(ShardConfig), C.POINTER(C.c_uint8), C.POINTER(_H)]),
+    "trag_shard_group_destroy": (None, [_H]),
+    "trag_shard_search_device": (C.c_int, [_H, _H, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trag_shard_fence": (C.c_int, [_H, C.c_void_p]),
+    "trag_shard_search_batch": (C.c_int, [_H, _H, C.c_uint32, C.c_uint32, _fp, C.c_uint32, C.c_uint32, C.c_uint32,
+                                          _u32p, _fp, _u32p]),
+    "trag_shard_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "trag_sharded_create": (C.c_int, [C.POINTER(Config), C.c_uint32, C.POINTER(C.c_int32), C.c_uint32,
+                                      C.POINTER(_H)]),
+    "trag_sharded_destroy": (None, [_H]),
+    "trag_sharded_insert": (C.c_int, [_H, _fp, C.c_uint64, C.c_uint32, _u32p]),
+    "trag_sharded_overwrite": (C.c_int, [_H, C.c_uint32, _fp, C.c_uint32]),
+    "trag_sharded_remove": (C.c_int, [_H, C.c_uint32]),
+    "trag_sharded_len": (C.c_uint64, [_H]),
+    "trag_sharded_rows": (C.c_uint64, [_H]),
+    "trag_sharded_search": (C.c_int, [_H, _fp, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "trag_sharded_search_batch": (C.c_int, [_H, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
+    "trag_sharded_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint64, _u32p]),
+    "trag_sharded_devices": (C.c_uint32, [_H]),
+    "trag_sharded_shard": (_H, [_H, C.c_uint32]),
     "trag_merge_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trag_pack_topk_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,

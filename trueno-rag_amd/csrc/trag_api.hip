@@ -21,18 +21,9 @@ using namespace trag;
 
 namespace {
 
-thread_local std::string g_last_error;
-
-trag_status fail(trag_status st, const std::string& msg) {
-    g_last_error = msg;
-    return st;
-}
+trag_status fail(trag_status st, const std::string& msg) { return trag::set_error(st, msg); }
 
 }  // namespace
-
-namespace trag {
-trag_status set_error(trag_status st, const std::string& msg) { return fail(st, msg); }
-}  // namespace trag
 
 namespace {
 
@@ -115,7 +106,20 @@ struct trag_store {
     float* d_out_scores = nullptr;
     uint32_t* d_out_n = nullptr;
     uint32_t* d_out_status = nullptr;
+    // Small inserts (the chunk-by-chunk `index()` loop of the retrievers, src/retrieve.rs:156-164)
+    // go through a pinned staging ring and return without waiting for the GPU; the per-row norms,
+    // the norm bound and the bf16 mirror of the rows in [dirty_from, n_rows) are brought up to date
+    // by ONE launch before the next search.
+    char* h_ring = nullptr;
+    size_t ring_bytes = 0, ring_pos = 0;
+    uint64_t dirty_from = ~0ull;
     hipStream_t stream = nullptr;
+    // The scratch holds one search at a time: when a call arrives on another stream than the one
+    // before it (a device-entry call on a caller's stream, then a host-entry call on `stream`, ...)
+    // the new stream first waits for everything enqueued on the old one.
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    hipEvent_t order_ev = nullptr;
     std::mutex mu;
     trag_search_stats stats{};
     // optional scan timing
@@ -161,19 +165,28 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
             return fail(TRAG_OOM, std::string("hipMalloc(bf16 mirror): ") + hipGetErrorString(e));
         }
     }
-    HIP_TRY(hipMemsetAsync(ndead, 0, dead_words * sizeof(uint32_t), s->stream));
-    if (s->n_rows && nmirror)
-        HIP_TRY(hipMemcpyAsync(nmirror, s->d_mirror, (size_t)s->n_rows * s->cfg.dim * sizeof(uint16_t),
-                               hipMemcpyDeviceToDevice, s->stream));
-    if (s->n_rows) {
-        HIP_TRY(hipMemcpyAsync(nnorm, s->d_norm2, (size_t)s->n_rows * sizeof(float),
-                               hipMemcpyDeviceToDevice, s->stream));
-        HIP_TRY(hipMemcpyAsync(nrows, s->d_rows, (size_t)s->n_rows * s->cfg.dim * sizeof(float),
-                               hipMemcpyDeviceToDevice, s->stream));
-        HIP_TRY(hipMemcpyAsync(ndead, s->d_dead, ((size_t)(s->n_rows + 31) / 32) * sizeof(uint32_t),
-                               hipMemcpyDeviceToDevice, s->stream));
+    e = hipMemsetAsync(ndead, 0, dead_words * sizeof(uint32_t), s->stream);
+    if (e == hipSuccess && s->n_rows && nmirror)
+        e = hipMemcpyAsync(nmirror, s->d_mirror, (size_t)s->n_rows * s->cfg.dim * sizeof(uint16_t),
+                           hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess && s->n_rows)
+        e = hipMemcpyAsync(nnorm, s->d_norm2, (size_t)s->n_rows * sizeof(float), hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess && s->n_rows)
+        e = hipMemcpyAsync(nrows, s->d_rows, (size_t)s->n_rows * s->cfg.dim * sizeof(float),
+                           hipMemcpyDeviceToDevice, s->stream);
+    if (e == hipSuccess && s->n_rows)
+        e = hipMemcpyAsync(ndead, s->d_dead, ((size_t)(s->n_rows + 31) / 32) * sizeof(uint32_t),
+                           hipMemcpyDeviceToDevice, s->stream);
+    // (the stream is drained on failure too: the copies above may still read the new buffers)
+    const hipError_t e_sync = hipStreamSynchronize(s->stream);
+    if (e == hipSuccess) e = e_sync;
+    if (e != hipSuccess) {   // the store keeps its old buffers; the new ones go back
+        (void)hipFree(nrows);
+        (void)hipFree(ndead);
+        (void)hipFree(nnorm);
+        if (nmirror) (void)hipFree(nmirror);
+        return fail(TRAG_DEVICE_ERROR, std::string("growing the store: ") + hipGetErrorString(e));
     }
-    HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_dead) (void)hipFree(s->d_dead);
     if (s->d_norm2) (void)hipFree(s->d_norm2);
@@ -418,6 +431,41 @@ hipError_t scan_timer_begin(trag_store* s, hipStream_t st, hipEvent_t* closing) 
     return hipEventRecord(pair.first, st);
 }
 
+// Orders work about to be enqueued on `st` behind whatever the handle enqueued last, if that
+// went to another stream: an event is recorded at the old stream's tail only then, so a caller
+// that stays on one stream pays nothing. Caller holds s->mu. (A stream handed to a _device entry
+// must not be destroyed before the handle's next call; if recording on it fails the device is
+// drained instead.)
+trag_status order_after_last(trag_store* s, hipStream_t st) {
+    if (s->has_last && s->last_stream != st && s->order_ev) {
+        hipError_t e = hipEventRecord(s->order_ev, s->last_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, s->order_ev, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    s->last_stream = st;
+    s->has_last = true;
+    return TRAG_OK;
+}
+
+// Derived data (squared norms, their bound, the bf16 mirror) of rows that small inserts appended
+// since the last search: one launch over the whole range, on the store's stream. Caller holds
+// s->mu and calls order_after_last() afterwards, which orders a search on another stream behind it.
+trag_status finish_inserts(trag_store* s) {
+    if (s->dirty_from >= s->n_rows) { s->dirty_from = ~0ull; return TRAG_OK; }
+    const uint64_t r0 = s->dirty_from, n = s->n_rows - r0;
+    const uint32_t dim = s->cfg.dim;
+    trag_status ts = order_after_last(s, s->stream);
+    if (ts != TRAG_OK) return ts;
+    float* dst = s->d_rows + (size_t)r0 * dim;
+    HIP_TRY(launch_update_vmax(dst, n, dim, s->d_vmax_sq, s->d_norm2 + r0, s->stream));
+    if (s->d_mirror) HIP_TRY(launch_to_bf16(dst, n * dim, s->d_mirror + (size_t)r0 * dim, s->stream));
+    s->dirty_from = ~0ull;
+    return TRAG_OK;
+}
+
 // Enqueue the pipeline for n_queries device-resident queries on `st`.
 // Caller holds s->mu, has set the device and made sure n_live > 0 and k > 0.
 
@@ -610,7 +658,6 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
 
 extern "C" {
 
-const char* trag_last_error(void) { return g_last_error.c_str(); }
 const char* trag_version(void) { return "trag-hip 0.1 (gfx950)"; }
 
 trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
@@ -633,7 +680,8 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
     s->device = dev;
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
-    e = hipMalloc(&s->d_vmax_sq, sizeof(float));
+    e = hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(&s->d_vmax_sq, sizeof(float));
     if (e == hipSuccess) e = hipMemsetAsync(s->d_vmax_sq, 0, sizeof(float), s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) { trag_store_destroy(s); return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
@@ -651,6 +699,7 @@ void trag_store_destroy(trag_store* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipDeviceSynchronize();
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (s->order_ev) (void)hipEventDestroy(s->order_ev);
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->d_mirror,
                     s->batch.qpad, s->batch.ctls, s->batch.keys, s->batch.tmax, s->batch.cand,
                     s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys,
@@ -660,6 +709,7 @@ void trag_store_destroy(trag_store* s) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (s->h_events) (void)hipHostFree(s->h_events);
+    if (s->h_ring) (void)hipHostFree(s->h_ring);
     if (s->h_q) (void)hipHostFree(s->h_q);
     if (s->h_out_block) (void)hipHostFree(s->h_out_block);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -696,6 +746,29 @@ trag_status trag_store_insert(trag_store* s, const float* rows, uint64_t n, uint
     trag_status ts = grow_rows(s, s->n_rows + n);
     if (ts != TRAG_OK) return ts;
     float* dst = s->d_rows + (size_t)s->n_rows * dim;
+    const size_t bytes = (size_t)n * dim * sizeof(float);
+    if (!s->h_ring) {
+        const size_t want = std::max<size_t>(1u << 20, (size_t)64 * dim * sizeof(float));
+        if (hipHostMalloc(reinterpret_cast<void**>(&s->h_ring), want, hipHostMallocDefault) == hipSuccess) s->ring_bytes = want;
+        else { s->h_ring = nullptr; (void)hipGetLastError(); }
+    }
+    if (s->h_ring && bytes <= s->ring_bytes / 4) {
+        // small insert: through the pinned ring, no wait (the ring's oldest bytes are reused only
+        // after the copies that read them have finished: one synchronisation per lap)
+        if (s->ring_pos + bytes > s->ring_bytes) {
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            s->ring_pos = 0;
+        }
+        trag_status to = order_after_last(s, s->stream);   // (a search may still be reading the corpus tail's neighbours: cheap, keeps one order)
+        if (to != TRAG_OK) return to;
+        std::memcpy(s->h_ring + s->ring_pos, rows, bytes);
+        HIP_TRY(hipMemcpyAsync(dst, s->h_ring + s->ring_pos, bytes, hipMemcpyHostToDevice, s->stream));
+        s->ring_pos += (bytes + 255) & ~(size_t)255;
+        s->dirty_from = std::min<uint64_t>(s->dirty_from, s->n_rows);
+        s->n_rows += n;
+        s->n_live += n;
+        return TRAG_OK;
+    }
     HIP_TRY(hipMemcpyAsync(dst, rows, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
     HIP_TRY(launch_update_vmax(dst, n, dim, s->d_vmax_sq, s->d_norm2 + s->n_rows, s->stream));
     if (s->d_mirror)
@@ -740,6 +813,13 @@ trag_status trag_store_remove(trag_store* s, uint32_t row) {
 
 trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
                                       uint64_t first_global_row, uint32_t* out_first_row) {
+    return trag::store_fill_synthetic(s, n, seed, first_global_row, 1, out_first_row);
+}
+
+}  // extern "C"
+
+trag_status trag::store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed, uint64_t first_global_row,
+                                       uint64_t row_step, uint32_t* out_first_row) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
@@ -750,7 +830,7 @@ trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
     float* d_norm = nullptr;
     HIP_TRY(hipMalloc(&d_norm, (size_t)n * sizeof(float)));
     float* dst = s->d_rows + (size_t)s->n_rows * s->cfg.dim;
-    hipError_t e = launch_fill_synthetic(dst, first_global_row, n, s->cfg.dim, seed, d_norm, s->stream);
+    hipError_t e = launch_fill_synthetic(dst, first_global_row, n, s->cfg.dim, seed, d_norm, s->stream, row_step);
     if (e == hipSuccess) e = launch_update_vmax(dst, n, s->cfg.dim, s->d_vmax_sq, s->d_norm2 + s->n_rows, s->stream);
     if (e == hipSuccess && s->d_mirror)
         e = launch_to_bf16(dst, n * s->cfg.dim, s->d_mirror + (size_t)s->n_rows * s->cfg.dim, s->stream);
@@ -762,11 +842,15 @@ trag_status trag_store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
     return TRAG_OK;
 }
 
+extern "C" {
+
 trag_status trag_store_read_rows(const trag_store* s, uint64_t row0, uint64_t n, float* out) {
     if (!s || (!out && n)) return fail(TRAG_INVALID_ARG, "null argument");
-    if (row0 + n > s->n_rows) return fail(TRAG_INVALID_ARG, "row range out of bounds");
+    std::lock_guard<std::mutex> lk(const_cast<trag_store*>(s)->mu);
+    if (row0 + n > s->n_rows || row0 + n < row0) return fail(TRAG_INVALID_ARG, "row range out of bounds");
     if (n == 0) return TRAG_OK;
     DeviceGuard guard(s->device);
+    HIP_TRY(hipStreamSynchronize(s->stream));   // small inserts are asynchronous copies on it
     HIP_TRY(hipMemcpy(out, s->d_rows + (size_t)row0 * s->cfg.dim, (size_t)n * s->cfg.dim * sizeof(float),
                       hipMemcpyDeviceToHost));
     return TRAG_OK;
@@ -791,6 +875,9 @@ trag_status trag_store_search_device(trag_store* s, const float* d_queries, uint
         if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, n_queries * sizeof(uint32_t), st));
         return TRAG_OK;
     }
+    trag_status ts = finish_inserts(s);
+    if (ts == TRAG_OK) ts = order_after_last(s, st);
+    if (ts != TRAG_OK) return ts;
     const uint32_t mode = choose_mode(s, n_queries, k);
     return enqueue_search(s, d_queries, n_queries, k, mode, d_out_rows, d_out_scores, d_out_n,
                           d_status, st);
@@ -812,9 +899,16 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
         return TRAG_OK;
     }
     DeviceGuard guard(s->device);
+    // the reference truncates to k, so any k is legal ("everything" = a huge k): buffers, kernels and
+    // the copy back are sized by the rows that can come back; the caller's arrays keep their stride k
+    const uint32_t k_user = k;
+    k = (uint32_t)std::min<uint64_t>(k, s->n_live);
     trag_status ts = ensure_staging(s, n_queries, k);
     if (ts != TRAG_OK) return ts;
     hipStream_t st = s->stream;
+    ts = finish_inserts(s);
+    if (ts == TRAG_OK) ts = order_after_last(s, st);
+    if (ts != TRAG_OK) return ts;
     // queries go up through pinned memory (a truly asynchronous copy), everything comes back in
     // ONE copy of the result block into pinned memory: rows, scores, counts, statuses and the
     // control block the diagnostics read (five pageable copies cost ~60 us per call)
@@ -836,8 +930,15 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
                                hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint32_t* h = s->h_out_block;
-        std::memcpy(out_rows, h, nk_words * sizeof(uint32_t));
-        std::memcpy(out_scores, h + nk_words, nk_words * sizeof(float));
+        if (k_user == k) {
+            std::memcpy(out_rows, h, nk_words * sizeof(uint32_t));
+            std::memcpy(out_scores, h + nk_words, nk_words * sizeof(float));
+        } else {
+            for (uint32_t b = 0; b < n_queries; ++b) {
+                std::memcpy(out_rows + (size_t)b * k_user, h + (size_t)b * k, k * sizeof(uint32_t));
+                std::memcpy(out_scores + (size_t)b * k_user, h + nk_words + (size_t)b * k, k * sizeof(float));
+            }
+        }
         std::memcpy(out_n, h + 2 * nk_words, n_queries * sizeof(uint32_t));
         std::memcpy(status.data(), h + 2 * nk_words + n_queries, n_queries * sizeof(uint32_t));
         std::memcpy(&ctl, h + res_words, sizeof(SearchCtl));
@@ -953,6 +1054,10 @@ trag_status trag_store_set_bf16_mirror(trag_store* s, int enabled) {
     }
     if (s->d_mirror) return TRAG_OK;
     if (s->cfg.dim % 8u) return fail(TRAG_UNSUPPORTED, "the bf16 mirror needs a dimension that is a multiple of 8");
+    {
+        trag_status tf = finish_inserts(s);
+        if (tf != TRAG_OK) return tf;
+    }
     const uint64_t cap = std::max<uint64_t>(s->cap_rows, 64);
     HIP_TRY(hipMalloc(&s->d_mirror, (size_t)cap * s->cfg.dim * sizeof(uint16_t)));
     if (s->cap_rows == 0) {

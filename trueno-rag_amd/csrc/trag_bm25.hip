@@ -159,6 +159,11 @@ struct trag_bm25 {
     uint32_t* d_out = nullptr;          // staging, laid out per call: k docs | k scores | n | status
     uint32_t* h_out = nullptr;          // its pinned host copy (one transfer per search)
     uint32_t out_cap_k = 0;
+    // one scratch, one accumulator array: a call on another stream than the call before it first
+    // waits for that call's work (as trag_store does)
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
+    hipEvent_t order_ev = nullptr;
 };
 
 namespace {
@@ -199,6 +204,9 @@ trag_status commit(trag_bm25* ix) {
         }
     }
     hipStream_t st = ix->stream;
+    // buffers may be replaced below: nothing enqueued earlier (device-entry searches on a
+    // caller's stream included) may still be using them
+    if (ix->d_post || ix->zero_block) BM_TRY(hipDeviceSynchronize());
     if (nnz > ix->post_cap) {
         if (ix->d_post) (void)hipFree(ix->d_post);
         ix->d_post = nullptr;
@@ -265,8 +273,18 @@ trag_status ensure_out(trag_bm25* ix, uint32_t k) {
 trag_status enqueue_query(trag_bm25* ix, const uint32_t* q_terms, uint32_t n_terms, uint32_t k,
                           uint32_t* d_docs, float* d_scores, uint32_t* d_n, uint32_t* d_status,
                           hipStream_t st) {
+    if (ix->has_last && ix->last_stream != st && ix->order_ev) {
+        hipError_t e = hipEventRecord(ix->order_ev, ix->last_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ix->order_ev, 0);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            BM_TRY(hipDeviceSynchronize());
+        }
+    }
+    ix->last_stream = st;
+    ix->has_last = true;
     if (ix->dirty) {
-        trag_status ts = commit(ix);
+        trag_status ts = commit(ix);   // (uploads on the index's own stream and waits for them)
         if (ts != TRAG_OK) return ts;
     }
     const uint32_t n_docs = (uint32_t)ix->n_docs_dev;
@@ -390,7 +408,9 @@ trag_status trag_bm25_create(const trag_bm25_config* cfg, trag_bm25** out) {
     ix->device = dev;
     DeviceScope guard(dev);
     hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->order_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
+        if (ix->stream) (void)hipStreamDestroy(ix->stream);
         delete ix;
         return set_error(TRAG_DEVICE_ERROR, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
@@ -404,6 +424,7 @@ void trag_bm25_destroy(trag_bm25* ix) {
         DeviceScope guard(ix->device);
         if (ix->stream) (void)hipStreamSynchronize(ix->stream);
         free_device(ix);
+        if (ix->order_ev) (void)hipEventDestroy(ix->order_ev);
         if (ix->stream) (void)hipStreamDestroy(ix->stream);
     }
     delete ix;
@@ -458,6 +479,8 @@ trag_status trag_bm25_search(trag_bm25* ix, const uint32_t* query_terms, uint32_
     *out_n = 0;
     if (k == 0 || n_terms == 0 || ix->n_live == 0) return TRAG_OK;  // src/index.rs:214-216
     DeviceScope guard(ix->device);
+    // any k is legal (the reference truncates): size everything by what can come back
+    k = (uint32_t)std::min<uint64_t>(k, ix->n_live);
     trag_status ts = ensure_out(ix, k);
     if (ts != TRAG_OK) return ts;
     hipStream_t st = ix->stream;

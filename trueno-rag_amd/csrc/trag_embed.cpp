@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "trag.h"
+#include "trag_error.h"
 
 namespace {
 
@@ -65,7 +66,7 @@ struct Sip13 {
 
 extern "C" trag_status trag_mock_embed(const char* text, uint64_t len, uint32_t dim, int normalize,
                                        float* out) {
-    if ((!text && len) || (!out && dim)) return TRAG_INVALID_ARG;
+    if ((!text && len) || (!out && dim)) return trag::set_error(TRAG_INVALID_ARG, "trag_mock_embed: null argument");
     Sip13 h;
     const unsigned char term = 0xFF;
     for (uint32_t i = 0; i < dim; ++i) {

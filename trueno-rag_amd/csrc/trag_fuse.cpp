@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "trag.h"
+#include "trag_error.h"
 
 namespace {
 
@@ -78,7 +79,9 @@ std::vector<float> z_score(const float* s, uint32_t n) {
     return out;
 }
 
-thread_local std::string g_fuse_error;
+trag_status bad(const char* fn, const char* what) {
+    return trag::set_error(TRAG_INVALID_ARG, std::string(fn) + ": " + what);
+}
 
 }  // namespace
 
@@ -88,12 +91,13 @@ trag_status trag_fuse(uint32_t strategy, float param, const uint64_t* dense_ids,
                       const float* dense_scores, uint32_t nd, const uint64_t* sparse_ids,
                       const float* sparse_scores, uint32_t ns, uint64_t* out_ids, float* out_scores,
                       uint32_t* out_n) {
-    if (!out_n) return TRAG_INVALID_ARG;
+    if (!out_n) return bad("trag_fuse", "out_n is null");
     *out_n = 0;
-    if ((nd && !dense_ids) || (ns && !sparse_ids) || ((nd + ns) && (!out_ids || !out_scores)))
-        return TRAG_INVALID_ARG;
-    if (strategy > 5) return TRAG_INVALID_ARG;
-    if (strategy != 0 && ((nd && !dense_scores) || (ns && !sparse_scores))) return TRAG_INVALID_ARG;
+    if ((nd && !dense_ids) || (ns && !sparse_ids)) return bad("trag_fuse", "a non-empty input list has no ids");
+    if ((nd + ns) && (!out_ids || !out_scores)) return bad("trag_fuse", "null output array");
+    if (strategy > 5) return bad("trag_fuse", "unknown strategy (0 RRF .. 5 Intersection)");
+    if (strategy != 0 && ((nd && !dense_scores) || (ns && !sparse_scores)))
+        return bad("trag_fuse", "this strategy reads the input scores, which are null");
     Accum acc;
     switch (strategy) {
     case 0: {  // RRF, src/fusion.rs:68-84: 1.0 / (k + rank as f32 + 1.0)
@@ -166,9 +170,9 @@ trag_status trag_fuse_rrf(const uint64_t* dense_ids, uint32_t nd, const uint64_t
 trag_status trag_merge_topk(const uint32_t* rows, const float* scores, const uint32_t* list_n,
                             uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t* out_rows,
                             float* out_scores, uint32_t* out_n) {
-    if (!out_n) return TRAG_INVALID_ARG;
+    if (!out_n) return bad("trag_merge_topk", "out_n is null");
     *out_n = 0;
-    if (n_lists && (!rows || !scores || !list_n)) return TRAG_INVALID_ARG;
+    if (n_lists && (!rows || !scores || !list_n)) return bad("trag_merge_topk", "null input array");
     std::vector<Entry> all;
     for (uint32_t l = 0; l < n_lists; ++l) {
         const uint32_t n = std::min(list_n[l], k_in);
@@ -178,7 +182,7 @@ trag_status trag_merge_topk(const uint32_t* rows, const float* scores, const uin
     }
     std::sort(all.begin(), all.end(), before);  // `order` = global row: a total order
     const uint32_t m = (uint32_t)std::min<size_t>(all.size(), k_out);
-    if (m && (!out_rows || !out_scores)) return TRAG_INVALID_ARG;
+    if (m && (!out_rows || !out_scores)) return bad("trag_merge_topk", "null output array");
     for (uint32_t i = 0; i < m; ++i) { out_rows[i] = (uint32_t)all[i].id; out_scores[i] = all[i].score; }
     *out_n = m;
     return TRAG_OK;

@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <string>
 #include "trag.h"
+#include "trag_error.h"
 
 namespace trag {
 
@@ -125,8 +126,11 @@ struct ScanArgs {
     uint32_t metric;
 };
 
-// Records the calling thread's error message (read back by trag_last_error) and returns st.
-trag_status set_error(trag_status st, const std::string& msg);
+
+// trag_store_fill_synthetic with a step between the generator rows: row i of the call is row
+// first_global_row + i * row_step of the generator's stream (shards striped over several GPUs)
+trag_status store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed, uint64_t first_global_row,
+                                 uint64_t row_step, uint32_t* out_first_row);
 
 // ---- kernel launchers (trag_kernels.hip) ----
 // the scans report the number of waves of their grid (tile t is scanned by wave t % n_waves)
@@ -190,17 +194,21 @@ hipError_t launch_select_mirror(const float* d_q, const ScanArgs& a, const Scrat
 hipError_t launch_bf16_finish(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const Bf16Scratch& s,
                               uint32_t live, uint32_t out_stride, uint32_t* d_out_rows, float* d_out_scores,
                               uint32_t* d_out_n, uint32_t* d_status, hipStream_t st);
+// row i of the call is row row0 + i * row_step of the generator's stream
 hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint32_t dim,
-                                 uint64_t seed, float* d_norm_tmp, hipStream_t st);
+                                 uint64_t seed, float* d_norm_tmp, hipStream_t st, uint64_t row_step = 1);
 hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_list_n,
                              uint32_t n_lists, uint32_t k_in, uint32_t k_out, uint32_t* d_out_rows,
                              float* d_out_scores, uint32_t* d_out_n, hipStream_t st);
+// global row = row0 + local row * row_mul; d_status (optional): per-query status of the local
+// search, carried in bits 16..23 of the record's count word
 hipError_t launch_pack_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_n,
                             uint32_t row0, uint32_t n_queries, uint32_t k, uint32_t* d_packed,
-                            hipStream_t st);
+                            hipStream_t st, uint32_t row_mul = 1, const uint32_t* d_status = nullptr);
+// d_out_status (optional): per query, the worst status any shard reported
 hipError_t launch_merge_packed(const uint32_t* d_gathered, uint32_t n_lists, uint32_t n_queries,
                                uint32_t k, uint32_t* d_out_rows, float* d_out_scores,
-                               uint32_t* d_out_n, hipStream_t st);
+                               uint32_t* d_out_n, hipStream_t st, uint32_t* d_out_status = nullptr);
 hipError_t launch_stream_probe(const float* d_rows, uint64_t n_floats, float* d_sink, hipStream_t st);
 hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
                               float* d_norm2_out, hipStream_t st);

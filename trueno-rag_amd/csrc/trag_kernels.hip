@@ -1523,19 +1523,21 @@ merge_topk_kernel(const uint32_t* __restrict__ rows, const float* __restrict__ s
     if (tid == 0) *out_n = n_out;
 }
 
-// Exchange record of one query: [k score bits | k global rows | count].
+// Exchange record of one query: [k score bits | k global rows | count]; the count word carries
+// the query's status on this shard in bits 16..23 (0 = final). Global row = row0 + local * row_mul
+// (contiguous shards: row_mul 1; shards striped over G ranks: row0 = rank, row_mul = G).
 __global__ void __launch_bounds__(256)
 pack_topk_kernel(const uint32_t* __restrict__ rows, const float* __restrict__ scores,
-                 const uint32_t* __restrict__ n, uint32_t row0, uint32_t n_queries, uint32_t k,
-                 uint32_t* __restrict__ packed) {
+                 const uint32_t* __restrict__ n, const uint32_t* __restrict__ status, uint32_t row0,
+                 uint32_t row_mul, uint32_t n_queries, uint32_t k, uint32_t* __restrict__ packed) {
     const uint32_t rec = 2u * k + 1u;
     const uint32_t total = n_queries * rec;
     for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
         const uint32_t q = e / rec, j = e - q * rec;
         uint32_t v;
         if (j < k) v = __float_as_uint(scores[(size_t)q * k + j]);
-        else if (j < 2u * k) v = rows[(size_t)q * k + (j - k)] + row0;
-        else v = n[q];
+        else if (j < 2u * k) v = rows[(size_t)q * k + (j - k)] * row_mul + row0;
+        else v = (n[q] & 0xFFFFu) | (status ? (status[q] & 0xFFu) << 16 : 0u);
         packed[e] = v;
     }
 }
@@ -1544,7 +1546,7 @@ pack_topk_kernel(const uint32_t* __restrict__ rows, const float* __restrict__ sc
 __global__ void __launch_bounds__(1024)
 merge_packed_kernel(const uint32_t* __restrict__ gathered, uint32_t n_lists, uint32_t n_queries,
                     uint32_t k, uint32_t* __restrict__ out_rows, float* __restrict__ out_scores,
-                    uint32_t* __restrict__ out_n) {
+                    uint32_t* __restrict__ out_n, uint32_t* __restrict__ out_status) {
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t total_sh;
     const int tid = threadIdx.x;
@@ -1555,13 +1557,19 @@ merge_packed_kernel(const uint32_t* __restrict__ gathered, uint32_t n_lists, uin
     while (P < C) P <<= 1;
     if (tid == 0) total_sh = 0;
     __syncthreads();
+    if (tid == 0 && out_status) {   // a query is final only if it is final on every shard
+        uint32_t worst = 0;
+        for (uint32_t l = 0; l < n_lists; ++l)
+            worst = max(worst, (gathered[((size_t)l * n_queries + q) * rec + 2u * k] >> 16) & 0xFFu);
+        out_status[q] = worst;
+    }
     uint32_t mine = 0;
     for (uint32_t i = tid; i < P; i += 1024u) {
         unsigned long long v = 0ull;
         if (i < C) {
             const uint32_t l = i / k, j = i - l * k;
             const uint32_t* r = gathered + ((size_t)l * n_queries + q) * rec;
-            const uint32_t cnt = min(r[2u * k], k);
+            const uint32_t cnt = min(r[2u * k] & 0xFFFFu, k);
             if (j < cnt) {
                 v = rank_key(score_key(__uint_as_float(r[j])), r[k + j]);
                 mine += 1;
@@ -1597,13 +1605,13 @@ merge_packed_kernel(const uint32_t* __restrict__ gathered, uint32_t n_lists, uin
 // normalisation per row (two passes so that the stores are coalesced).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-synth_norm_kernel(unsigned long long seed, unsigned long long row0, unsigned long long n,
-                  uint32_t d, float* __restrict__ norms) {
+synth_norm_kernel(unsigned long long seed, unsigned long long row0, unsigned long long row_step,
+                  unsigned long long n, uint32_t d, float* __restrict__ norms) {
     const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
     if (i >= n) return;
     float ss = 0.0f;
     for (uint32_t c = 0; c < d; ++c) {
-        const float v = synth_component(seed, row0 + i, c);
+        const float v = synth_component(seed, row0 + i * row_step, c);
         const float p = v * v;
         ss = ss + p;
     }
@@ -1611,14 +1619,14 @@ synth_norm_kernel(unsigned long long seed, unsigned long long row0, unsigned lon
 }
 
 __global__ void __launch_bounds__(256)
-synth_fill_kernel(unsigned long long seed, unsigned long long row0, unsigned long long n,
-                  uint32_t d, const float* __restrict__ norms, float* __restrict__ rows) {
+synth_fill_kernel(unsigned long long seed, unsigned long long row0, unsigned long long row_step,
+                  unsigned long long n, uint32_t d, const float* __restrict__ norms, float* __restrict__ rows) {
     const unsigned long long total = n * (unsigned long long)d;
     for (unsigned long long e = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; e < total;
          e += (unsigned long long)gridDim.x * 256ull) {
         const unsigned long long i = e / d;
         const uint32_t c = (uint32_t)(e - i * d);
-        float v = synth_component(seed, row0 + i, c);
+        float v = synth_component(seed, row0 + i * row_step, c);
         const float nrm = norms[i];
         if (nrm > 0.0f) v = v / nrm;
         rows[e] = v;
@@ -2000,12 +2008,12 @@ hipError_t launch_scan_exact_multi(const float* d_q, uint32_t n_queries, const S
 }
 
 hipError_t launch_fill_synthetic(float* d_rows, uint64_t row0, uint64_t n, uint32_t dim,
-                                 uint64_t seed, float* d_norm_tmp, hipStream_t st) {
+                                 uint64_t seed, float* d_norm_tmp, hipStream_t st, uint64_t row_step) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(synth_norm_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, seed,
-                       row0, n, dim, d_norm_tmp);
+                       row0, row_step, n, dim, d_norm_tmp);
     const uint32_t grid = grid_for(n * dim, 256 * 8, 256 * 16);
-    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, st, seed, row0, n, dim,
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(grid), dim3(256), 0, st, seed, row0, row_step, n, dim,
                        d_norm_tmp, d_rows);
     return hipGetLastError();
 }
@@ -2020,18 +2028,18 @@ hipError_t launch_merge_topk(const uint32_t* d_rows, const float* d_scores, cons
 
 hipError_t launch_pack_topk(const uint32_t* d_rows, const float* d_scores, const uint32_t* d_n,
                             uint32_t row0, uint32_t n_queries, uint32_t k, uint32_t* d_packed,
-                            hipStream_t st) {
+                            hipStream_t st, uint32_t row_mul, const uint32_t* d_status) {
     const uint32_t grid = grid_for((uint64_t)n_queries * (2 * k + 1), 256, 1024);
-    hipLaunchKernelGGL(pack_topk_kernel, dim3(grid), dim3(256), 0, st, d_rows, d_scores, d_n, row0,
-                       n_queries, k, d_packed);
+    hipLaunchKernelGGL(pack_topk_kernel, dim3(grid), dim3(256), 0, st, d_rows, d_scores, d_n, d_status, row0,
+                       row_mul, n_queries, k, d_packed);
     return hipGetLastError();
 }
 
 hipError_t launch_merge_packed(const uint32_t* d_gathered, uint32_t n_lists, uint32_t n_queries,
                                uint32_t k, uint32_t* d_out_rows, float* d_out_scores,
-                               uint32_t* d_out_n, hipStream_t st) {
+                               uint32_t* d_out_n, hipStream_t st, uint32_t* d_out_status) {
     hipLaunchKernelGGL(merge_packed_kernel, dim3(n_queries), dim3(1024), 0, st, d_gathered, n_lists,
-                       n_queries, k, d_out_rows, d_out_scores, d_out_n);
+                       n_queries, k, d_out_rows, d_out_scores, d_out_n, d_out_status);
     return hipGetLastError();
 }
 

@@ -233,6 +233,7 @@ class VectorStore:
         dim = self._config.dimension
         if q.size != dim:
             raise _abi.DimensionMismatch(dim, int(q.size))
+        k = min(int(k), self.len())   # the reference truncates: any k is legal, at most len() rows come back
         rows = np.empty(max(k, 1), dtype=np.uint32)
         scores = np.empty(max(k, 1), dtype=np.float32)
         n = C.c_uint32()
@@ -249,6 +250,7 @@ class VectorStore:
         if Q.shape[1] != dim:
             raise _abi.DimensionMismatch(dim, int(Q.shape[1]))
         B = Q.shape[0]
+        k = min(int(k), self.len())
         rows = np.zeros((B, max(k, 1)), dtype=np.uint32)
         scores = np.zeros((B, max(k, 1)), dtype=np.float32)
         n = np.zeros(B, dtype=np.uint32)

@@ -77,8 +77,13 @@ class ShardExchange:
                 stream.synchronize()
                 self.dist.all_gather_into_tensor(hg, hp, group=self.group)
                 gathered.copy_(hg, non_blocking=True)
-        elif self.world > 1:
-            self.dist.all_gather_into_tensor(gathered, pack, group=self.group)
+        elif self.dist.is_initialized():
+            # (also with one rank: the collective still runs, RCCL on a GPU)
+            if stream_ptr and self.device.type == "cuda":
+                with t.cuda.stream(t.cuda.ExternalStream(stream_ptr)):
+                    self.dist.all_gather_into_tensor(gathered, pack, group=self.group)
+            else:
+                self.dist.all_gather_into_tensor(gathered, pack, group=self.group)
         else:
             gathered.copy_(pack)
         if self.device.type == "cuda":
@@ -92,7 +97,7 @@ class ShardExchange:
             for b in range(B):
                 g_scores = np.ascontiguousarray(g[:, b, :k]).view(np.float32)
                 g_rows = np.ascontiguousarray(g[:, b, k:2 * k]).astype(np.uint32)
-                g_n = np.ascontiguousarray(g[:, b, 2 * k]).astype(np.uint32)
+                g_n = (np.ascontiguousarray(g[:, b, 2 * k]) & 0xFFFF).astype(np.uint32)  # (bits 16..23: status)
                 o_r, o_s, o_n = np.zeros(k, np.uint32), np.zeros(k, np.float32), C.c_uint32()
                 _abi.check(L.trag_merge_topk(g_rows.ctypes.data_as(u32p), g_scores.ctypes.data_as(fp),
                                              g_n.ctypes.data_as(u32p), self.world, k, k,
@@ -183,3 +188,159 @@ class ShardedVectorStore:
     def search_rows(self, query, k: int):
         r, s, n = self.search_batch_rows(np.asarray(query, dtype=np.float32)[None, :], k)
         return r[0, :n[0]], s[0, :n[0]]
+
+
+class ShardGroup:
+    """One rank of a row-sharded search through the C ABI (trag_shard_group_*): the library
+    itself runs pack -> RCCL all-gather -> merge, one C call per step. The ranks meet through an
+    RCCL unique id that rank 0 creates and `share_id` carries to the others (by default over the
+    torch.distributed default group, which may be gloo: the id is 128 bytes of host memory)."""
+
+    def __init__(self, rank: int, world: int, device: int, k_max: int, max_queries: int = 1,
+                 overlap: bool = False, unique_id: bytes = None, share_id=None):
+        L = _abi.lib()
+        if unique_id is None:
+            buf = (C.c_uint8 * _abi.SHARD_ID_BYTES)()
+            if rank == 0:
+                _abi.check(L.trag_shard_unique_id(buf))
+            raw = bytes(buf)
+            if world > 1:
+                raw = (share_id or self._broadcast_id)(raw, rank)
+            unique_id = raw
+        assert len(unique_id) == _abi.SHARD_ID_BYTES
+        self.rank, self.world, self.k_max, self.max_queries = rank, world, k_max, max_queries
+        cfg = _abi.ShardConfig(rank, world, device, k_max, max_queries, 1 if overlap else 0)
+        idbuf = (C.c_uint8 * _abi.SHARD_ID_BYTES).from_buffer_copy(unique_id)
+        self._h = _abi._H()
+        _abi.check(L.trag_shard_group_create(C.byref(cfg), idbuf, C.byref(self._h)))
+
+    @staticmethod
+    def _broadcast_id(raw: bytes, rank: int) -> bytes:
+        import torch.distributed as dist
+        box = [raw if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _abi.lib().trag_shard_group_destroy(self._h)
+            self._h = _abi._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_device(self, store, row0: int, row_mul: int, d_queries_ptr: int, n_queries: int, k: int,
+                      d_rows_ptr: int, d_scores_ptr: int, d_n_ptr: int, d_status_ptr: int = 0, stream: int = 0):
+        """Collective. Local search on `store` + exchange + merge, enqueued on `stream`; every rank's
+        output arrays receive the global top k (global row = row0 + local row * row_mul)."""
+        dim = store.config().dimension
+        _abi.check(_abi.lib().trag_shard_search_device(
+            self._h, store.handle, row0, row_mul, C.c_void_p(d_queries_ptr), n_queries, dim, k,
+            C.c_void_p(d_rows_ptr), C.c_void_p(d_scores_ptr), C.c_void_p(d_n_ptr),
+            C.c_void_p(d_status_ptr) if d_status_ptr else None, C.c_void_p(stream) if stream else None), dim, dim)
+
+    def fence(self, stream: int = 0):
+        _abi.check(_abi.lib().trag_shard_fence(self._h, C.c_void_p(stream) if stream else None))
+
+    def search_batch_rows(self, store, row0: int, row_mul: int, queries, k: int):
+        """Collective, host arrays, synchronous: (global rows [B, k], scores [B, k], counts [B])."""
+        Q = np.ascontiguousarray(queries, dtype=np.float32)
+        B, dim = Q.shape
+        rows = np.zeros((B, max(k, 1)), dtype=np.uint32)
+        scores = np.zeros((B, max(k, 1)), dtype=np.float32)
+        n = np.zeros(B, dtype=np.uint32)
+        u32p, fp = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+        _abi.check(_abi.lib().trag_shard_search_batch(
+            self._h, store.handle, row0, row_mul, Q.ctypes.data_as(fp), B, dim, k, rows.ctypes.data_as(u32p),
+            scores.ctypes.data_as(fp), n.ctypes.data_as(u32p)), store.config().dimension, dim)
+        return rows[:, :k], scores[:, :k], n
+
+
+def rccl_version() -> int:
+    v = C.c_int(0)
+    _abi.check(_abi.lib().trag_shard_rccl_version(C.byref(v)))
+    return v.value
+
+
+class MultiGpuVectorStore:
+    """One process, several GPUs (trag_sharded_*): a store striped by rows over `devices`, one RCCL
+    communicator over all of them (exchange="rccl"), or plain device-to-device copies
+    (exchange="copy": no RCCL needed, and the same GPU may be named twice). Row-level surface of
+    VectorStore: insert_rows / search_rows / search_batch_rows / remove_row / len."""
+
+    def __init__(self, config, devices, exchange: str = "rccl"):
+        self._config = config
+        cfg = _abi.Config(config.dimension, int(config.metric), -1, config.scan_mode, config.reserve_rows)
+        ids = (C.c_int32 * len(devices))(*devices)
+        self._h = _abi._H()
+        _abi.check(_abi.lib().trag_sharded_create(C.byref(cfg), len(devices), ids,
+                                                  {"rccl": 0, "copy": 1}[exchange], C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _abi.lib().trag_sharded_destroy(self._h)
+            self._h = _abi._H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def config(self):
+        return self._config
+
+    def insert_rows(self, rows) -> int:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        first = C.c_uint32()
+        _abi.check(_abi.lib().trag_sharded_insert(self._h, rows.ctypes.data_as(C.POINTER(C.c_float)), rows.shape[0],
+                                                  rows.shape[1], C.byref(first)), self._config.dimension, rows.shape[1])
+        return first.value
+
+    def fill_synthetic(self, n: int, seed: int) -> int:
+        first = C.c_uint32()
+        _abi.check(_abi.lib().trag_sharded_fill_synthetic(self._h, n, seed, C.byref(first)))
+        return first.value
+
+    def overwrite_row(self, row: int, vec) -> None:
+        v = np.ascontiguousarray(vec, dtype=np.float32).reshape(-1)
+        _abi.check(_abi.lib().trag_sharded_overwrite(self._h, row, v.ctypes.data_as(C.POINTER(C.c_float)), v.size),
+                   self._config.dimension, v.size)
+
+    def remove_row(self, row: int) -> None:
+        _abi.check(_abi.lib().trag_sharded_remove(self._h, row))
+
+    def len(self) -> int:
+        return int(_abi.lib().trag_sharded_len(self._h))
+
+    def rows(self) -> int:
+        return int(_abi.lib().trag_sharded_rows(self._h))
+
+    def shard_handle(self, i: int):
+        return _abi._H(_abi.lib().trag_sharded_shard(self._h, i))
+
+    def set_scan_mode(self, mode: int) -> None:
+        for i in range(_abi.lib().trag_sharded_devices(self._h)):
+            _abi.check(_abi.lib().trag_store_set_scan_mode(self.shard_handle(i), mode))
+
+    def search_batch_rows(self, queries, k: int):
+        Q = np.ascontiguousarray(queries, dtype=np.float32)
+        if Q.ndim != 2:
+            raise _abi.InvalidConfig("queries must be a 2-D array")
+        B, dim = Q.shape
+        k = min(int(k), self.len())
+        rows = np.zeros((B, max(k, 1)), dtype=np.uint32)
+        scores = np.zeros((B, max(k, 1)), dtype=np.float32)
+        n = np.zeros(B, dtype=np.uint32)
+        u32p, fp = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+        _abi.check(_abi.lib().trag_sharded_search_batch(self._h, Q.ctypes.data_as(fp), B, dim, k,
+                                                        rows.ctypes.data_as(u32p), scores.ctypes.data_as(fp),
+                                                        n.ctypes.data_as(u32p)), self._config.dimension, dim)
+        return rows[:, :k], scores[:, :k], n
+
+    def search_rows(self, query, k: int):
+        r, s, n = self.search_batch_rows(np.asarray(query, dtype=np.float32)[None, :], k)
+        return r[0, :n[0]].copy(), s[0, :n[0]].copy()

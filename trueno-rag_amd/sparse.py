@@ -106,6 +106,18 @@ class BM25Index:
     def add_batch(self, chunks: List[Chunk]) -> None:
         if not chunks:
             return
+        # Re-adding a ChunkId REPLACES its document. (The reference keeps both postings, counts the
+        # chunk twice in doc_count and df while doc_lengths holds one entry, and scores it once from
+        # the first posting's tf and the newer length, src/index.rs:176-204,127-133; that
+        # bookkeeping is not reproduced: a chunk is one document here, so a search never returns an
+        # id twice and fuse never counts it twice.)
+        if len({c.id for c in chunks}) != len(chunks):   # the same id twice in one batch: one by one
+            for c in chunks:
+                self.add_batch([c])
+            return
+        for c in chunks:
+            if c.id in self._doc_of:
+                self.remove(c.id)
         seqs = [self._ids(self.tokenize(c.content), True) for c in chunks]
         off = np.zeros(len(seqs) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(s) for s in seqs])
@@ -140,6 +152,7 @@ class BM25Index:
     def search_ids(self, query_terms, k: int) -> Tuple[np.ndarray, np.ndarray]:
         """Search with a tokenised query; returns (document indices, scores)."""
         q = np.ascontiguousarray(query_terms, dtype=np.uint32)
+        k = min(int(k), self.len())   # the reference truncates: any k is legal
         docs = np.zeros(max(k, 1), dtype=np.uint32)
         scores = np.zeros(max(k, 1), dtype=np.float32)
         n = C.c_uint32(0)
