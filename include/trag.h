@@ -145,6 +145,22 @@ trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint
                                      float *d_out_scores, uint32_t *d_out_n,
                                      uint32_t *d_status, void *hip_stream);
 
+/* No counterpart in the reference. For callers that cannot allocate device memory -- code
+ * under HIP graph capture, serving loops with a frozen memory plan, harnesses that forbid
+ * hipMalloc: trag_store_search_device for single-query exact scans with the search scratch
+ * (per-row keys, tile and wave maxima, histograms, candidate lists) in a fixed 65.3 MB device
+ * array inside the library instead of per-handle allocations. Same arguments, results,
+ * d_status codes and ordering rule; queries are scanned one at a time in the reference's
+ * summation order (no matrix-core or mirror route). It calls no hipMalloc / hipFree / event or
+ * stream creation. Limits: at most 16 777 216 rows ever inserted in the store and k <= 4064
+ * (unless the store holds <= 4096 live rows), else TRAG_UNSUPPORTED. All calls on one GPU share
+ * that GPU's array, across stores: calls whose GPU work overlaps (two streams, two threads with
+ * two stores) race and return garbage -- keep them on one stream or order them with events. */
+trag_status trag_store_search_device_noalloc(trag_store *s, const float *d_queries,
+                                             uint32_t n_queries, uint32_t dim, uint32_t k,
+                                             uint32_t *d_out_rows, float *d_out_scores,
+                                             uint32_t *d_out_n, uint32_t *d_status, void *hip_stream);
+
 /* Append n rows produced on the device by the library's counter-based
  * synthetic generator (seeded, unit-norm rows); used by benchmarks so that a
  * multi-GB corpus never crosses PCIe. Row i of the call is row

@@ -71,6 +71,8 @@ SIGNATURES = {
     "trag_store_search_batch": (C.c_int, [_H, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
     "trag_store_search_device": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trag_store_search_device_noalloc": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trag_store_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.c_uint64, _u32p]),
     "trag_shard_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "trag_shard_group_create": (C.c_int, [C.POINTER(ShardConfig), C.POINTER(C.c_uint8), C.POINTER(_H)]),

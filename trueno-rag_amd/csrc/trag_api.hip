@@ -656,7 +656,149 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// trag_store_search_device_noalloc: the search scratch in a fixed device array
+// ---------------------------------------------------------------------------
+// Callers that cannot allocate (HIP graph capture, serving loops with a frozen memory plan) get the
+// single-query pipeline with its scratch -- control block + histograms, wave maxima, candidate
+// lists, published wave bests, tile maxima and the per-row keys -- laid out in ONE device array of
+// fixed size that every GPU running this library holds from the load of the code object to the end
+// of the process: 4 bytes per row for up to NOALLOC_MAX_ROWS rows, about 65.3 MB in all. Every
+// call on a GPU shares that GPU's copy, whatever the store: calls that overlap on one GPU race.
+namespace {
+constexpr uint64_t NOALLOC_MAX_ROWS = 16ull << 20;   // 16 Mi rows: the 10M-row headline corpus fits
+constexpr size_t NA_CTL_WORDS = 64;                  // the control block padded to 256 bytes
+constexpr size_t NA_ZERO_WORDS = NA_CTL_WORDS + (size_t)HIST_LEVELS * HIST_BINS;
+constexpr size_t NA_WMAX = NA_ZERO_WORDS;
+constexpr size_t NA_CAND = NA_WMAX + WMAX_CAP;
+constexpr size_t NA_CKEYS = NA_CAND + CAND_CAP;
+constexpr size_t NA_WBEST = NA_CKEYS + CAND_CAP;     // 64-bit entries: an even word offset
+constexpr size_t NA_TMAX = NA_WBEST + 2 * (size_t)SPARSE_WAVES;
+constexpr size_t NA_KEYS = NA_TMAX + NOALLOC_MAX_ROWS / 64 + 64;
+constexpr size_t NA_WORDS = NA_KEYS + NOALLOC_MAX_ROWS;
+static_assert(sizeof(SearchCtl) <= NA_CTL_WORDS * 4, "control block grew");
+static_assert(NA_WBEST % 2 == 0 && NA_TMAX % 64 == 0 && NA_KEYS % 64 == 0, "sections lose their alignment");
+}  // namespace
+
+static __device__ __align__(256) uint32_t scratch[NA_WORDS];
+
+namespace {
+
+// One entry per device ordinal: the device address of that GPU's copy of `scratch` (each GPU has
+// its own, at its own address), looked up once with that device current, and the tag counter of
+// the sparse key stores (the published wave bests in the array are shared by every handle).
+struct NoAllocDevice {
+    uint32_t* base = nullptr;
+    hipError_t lookup = hipErrorNotInitialized;
+    uint32_t epoch = 0;
+};
+constexpr int NOALLOC_MAX_DEVICES = 64;
+NoAllocDevice g_noalloc[NOALLOC_MAX_DEVICES];
+std::mutex g_noalloc_mu;
+
+// Device `dev` must be current. Host code never uses the array's name as an address: only the
+// pointer hipGetSymbolAddress returns for this device.
+trag_status noalloc_setup(int dev) {
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail(TRAG_UNSUPPORTED, "device ordinal beyond the no-allocation table");
+    std::lock_guard<std::mutex> lk(g_noalloc_mu);
+    NoAllocDevice& nd = g_noalloc[dev];
+    if (nd.base) return TRAG_OK;
+    void* p = nullptr;
+    nd.lookup = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (nd.lookup != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return fail(TRAG_DEVICE_ERROR, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(nd.lookup));
+    }
+    nd.base = static_cast<uint32_t*>(p);
+    return TRAG_OK;
+}
+
+}  // namespace
+
 extern "C" {
+
+trag_status trag_store_search_device_noalloc(trag_store* s, const float* d_queries, uint32_t n_queries,
+                                             uint32_t dim, uint32_t k, uint32_t* d_out_rows,
+                                             float* d_out_scores, uint32_t* d_out_n, uint32_t* d_status,
+                                             void* hip_stream) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    if (dim != s->cfg.dim)
+        return fail(TRAG_DIM_MISMATCH, "dimension mismatch: expected " + std::to_string(s->cfg.dim) +
+                                           ", got " + std::to_string(dim));
+    if (n_queries == 0) return TRAG_OK;
+    if (!d_queries || !d_out_n || (k && (!d_out_rows || !d_out_scores)))
+        return fail(TRAG_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (k == 0 || s->n_live == 0) {
+        HIP_TRY(hipMemsetAsync(d_out_n, 0, n_queries * sizeof(uint32_t), st));
+        if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, n_queries * sizeof(uint32_t), st));
+        return TRAG_OK;
+    }
+    if (s->n_rows > NOALLOC_MAX_ROWS)
+        return fail(TRAG_UNSUPPORTED, "store holds " + std::to_string(s->n_rows) + " rows, the fixed scratch of this "
+                                      "entry point " + std::to_string(NOALLOC_MAX_ROWS) + " at most");
+    const uint32_t live = (uint32_t)s->n_live;
+    const uint32_t k_eff = std::min<uint32_t>(k, live);
+    if (k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP)
+        return fail(TRAG_UNSUPPORTED, "k above " + std::to_string(CAND_CAP - STREAM_SLACK) +
+                                      " needs the global sort's buffer (use trag_store_search_device)");
+    trag_status ts = noalloc_setup(s->device);   // (a lookup only, and only if create could not do it)
+    if (ts != TRAG_OK) return ts;
+    std::lock_guard<std::mutex> lk2(g_noalloc_mu);   // one enqueue at a time per process: the tag counter
+    NoAllocDevice& nd = g_noalloc[s->device];
+    Scratch sc{};
+    sc.ctl = reinterpret_cast<SearchCtl*>(nd.base);
+    sc.hist = nd.base + NA_CTL_WORDS;
+    sc.wmax = nd.base + NA_WMAX;
+    sc.cand = nd.base + NA_CAND;
+    sc.ckeys = nd.base + NA_CKEYS;
+    sc.wbest = reinterpret_cast<unsigned long long*>(nd.base + NA_WBEST);
+    sc.tmax = nd.base + NA_TMAX;
+    sc.keys = nd.base + NA_KEYS;
+    sc.events = nullptr;   // no pinned word here: this entry follows the plan the handle has, it learns none
+    ts = finish_inserts(s);   // (kernel launches only)
+    if (ts == TRAG_OK) ts = order_after_last(s, st);
+    if (ts != TRAG_OK) return ts;
+    // the array keeps what the last call left, possibly of another store or of a call that failed
+    // half way: the accumulators start from zero (keys, tile and wave maxima are rewritten by every
+    // scan for every row they are read for; the published wave bests are told apart by their tag)
+    HIP_TRY(hipMemsetAsync(nd.base, 0, NA_ZERO_WORDS * sizeof(uint32_t), st));
+    if (s->sparse_keys < 0) {
+        const char* e = getenv("TRAG_SPARSE_KEYS");
+        s->sparse_keys = (e && e[0] == '0') ? 0 : 1;
+    }
+    const size_t hist_bytes = (size_t)HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
+    ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+    for (uint32_t b = 0; b < n_queries; ++b) {
+        const float* q = d_queries + (size_t)b * dim;
+        sc.epoch = 0;
+        if (s->sparse_keys && !s->full_select) {
+            if (++nd.epoch == 0u) {
+                nd.epoch = 1;
+                HIP_TRY(hipMemsetAsync(sc.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st));
+            }
+            sc.epoch = nd.epoch;
+        }
+        uint32_t n_waves = 0;
+        HIP_TRY(launch_scan_exact(q, a, sc, k_eff, k_eff, s->d_vmax_sq, &n_waves, st));
+        uint32_t* o_rows = d_out_rows + (size_t)b * k;
+        float* o_scores = d_out_scores + (size_t)b * k;
+        uint32_t* o_status = d_status ? d_status + b : nullptr;
+        if (!s->full_select) {
+            HIP_TRY(launch_select_final(q, a, sc, false, live, k_eff, k_eff, n_waves, o_rows, o_scores,
+                                        d_out_n + b, o_status, st));
+        } else {
+            HIP_TRY(launch_select(a, sc, st));
+            HIP_TRY(launch_final(q, a, sc, false, live, o_rows, o_scores, d_out_n + b, o_status, st));
+            HIP_TRY(hipMemsetAsync(sc.hist, 0, hist_bytes, st));
+            HIP_TRY(launch_reset_ctl(sc, st));
+        }
+    }
+    s->stats.mode_used = TRAG_SCAN_EXACT;
+    return TRAG_OK;
+}
 
 const char* trag_version(void) { return "trag-hip 0.1 (gfx950)"; }
 
@@ -689,6 +831,9 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
         trag_status ts = grow_rows(s, cfg->reserve_rows);
         if (ts != TRAG_OK) { trag_store_destroy(s); return ts; }
     }
+    // set-up of the fixed scratch of trag_store_search_device_noalloc on this device (its address is
+    // looked up once per device; a failure is reported by that entry point, not here)
+    (void)noalloc_setup(dev);
     *out = s;
     return TRAG_OK;
 }

@@ -213,6 +213,15 @@ class VectorStore:
             C.c_void_p(d_scores_ptr), C.c_void_p(d_n_ptr), C.c_void_p(d_status_ptr) if d_status_ptr else None,
             C.c_void_p(stream) if stream else None), self._config.dimension, self._config.dimension)
 
+    def search_device_noalloc(self, d_queries_ptr: int, n_queries: int, k: int, d_rows_ptr: int,
+                              d_scores_ptr: int, d_n_ptr: int, d_status_ptr: int = 0, stream: int = 0) -> None:
+        """search_device for callers that cannot allocate: exact single-query scans whose scratch is
+        the library's fixed device array (shared by every store on the GPU)."""
+        _abi.check(_abi.lib().trag_store_search_device_noalloc(
+            self._h, C.c_void_p(d_queries_ptr), n_queries, self._config.dimension, k, C.c_void_p(d_rows_ptr),
+            C.c_void_p(d_scores_ptr), C.c_void_p(d_n_ptr), C.c_void_p(d_status_ptr) if d_status_ptr else None,
+            C.c_void_p(stream) if stream else None), self._config.dimension, self._config.dimension)
+
     def read_rows(self, row0: int, n: int) -> np.ndarray:
         out = np.empty((n, self._config.dimension), dtype=np.float32)
         _abi.check(_abi.lib().trag_store_read_rows(self._h, row0, n, _fptr(out)))
