@@ -632,7 +632,8 @@ BF16 = 4
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("n,d,B", [(70_000, 384, 9), (100_000, 768, 40), (66_000, 64, 100), (80_000, 128, 200),
-                                   (131_072, 256, 300)])
+                                   (131_072, 256, 300), (70_001, 384, 130), (100_003, 384, 600),
+                                   (66_000, 128, 2100)])
 def test_bf16_prefilter_parity(trag, oracle, metric, n, d, B):
     rng = np.random.default_rng(n + d + B)
     corpus = unit_rows(rng, n, d) if metric == 0 else rng.standard_normal((n, d)).astype(np.float32)

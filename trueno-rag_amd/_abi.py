@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "lib", "libtrag.so")
+# TRAG_LIB names another build of the same library (kernel experiments); never a fallback
+_LIB = os.environ.get("TRAG_LIB") or os.path.join(_HERE, "lib", "libtrag.so")
 
 OK, DIM_MISMATCH, INVALID_CONFIG, DEVICE_ERROR, OOM, INVALID_ARG, UNSUPPORTED = range(7)
 

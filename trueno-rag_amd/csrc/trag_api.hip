@@ -333,7 +333,7 @@ trag_status ensure_batch_scratch(trag_store* s, uint32_t nq) {
 }
 
 trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
-    const uint32_t qcap = std::min<uint32_t>(std::max<uint32_t>(nq, 1), BATCH_QUERIES);
+    const uint32_t qcap = std::min<uint32_t>(std::max<uint32_t>(nq, 1), bf16_max_batch(s->cfg.dim, s->cfg.metric, nq));
     const uint64_t tiles = (uint64_t)s->cap_rows / 32 + 32;  // one maximum per 32 rows, sample step 1 at worst
     if (s->bf16.qb && s->bf16_tiles_cap >= tiles && s->bf16_q_cap >= qcap) return TRAG_OK;
     void* old[] = {s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys};
@@ -534,8 +534,11 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         ts = ensure_bf16_scratch(s, n_queries);
         if (ts != TRAG_OK) return ts;
         ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
-        for (uint32_t b0 = 0; b0 < n_queries; b0 += BATCH_QUERIES) {
-            const uint32_t nb = std::min<uint32_t>(BATCH_QUERIES, n_queries - b0);
+        // one corpus pass per chunk: the query-stationary form takes the whole batch (up to 2048
+        // queries) in one, the tiled form 256 at a time
+        const uint32_t chunk = bf16_max_batch(s->cfg.dim, s->cfg.metric, n_queries);
+        for (uint32_t b0 = 0; b0 < n_queries; b0 += chunk) {
+            const uint32_t nb = std::min<uint32_t>(chunk, n_queries - b0);
             const float* Qb = d_queries + (size_t)b0 * s->cfg.dim;
             hipEvent_t e1 = nullptr;
             HIP_TRY(scan_timer_begin(s, st, &e1));

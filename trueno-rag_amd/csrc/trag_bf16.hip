@@ -494,12 +494,48 @@ static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArg
     launch_gemm_bf16<METRIC, 1, MIR>(n_queries, a, d_mirror, d_norm2, s, 1, st);
 }
 
+void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padded, uint32_t dim, uint16_t* qb,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min<uint32_t>(1024, (padded * dim / 4 + 255) / 256)),
+                       dim3(256), 0, st, d_Q, n_queries, padded, dim, reinterpret_cast<__bf16*>(qb));
+}
+
+void launch_shift_threshold(uint32_t metric, SearchCtl* ctls, uint32_t n_queries, uint32_t dim, float* thr,
+                            hipStream_t st) {
+    const dim3 grid((n_queries + 255) / 256), block(256);
+    if (metric == TRAG_COSINE) hipLaunchKernelGGL(shift_threshold_kernel<0>, grid, block, 0, st, ctls, n_queries, dim, thr);
+    else if (metric == TRAG_EUCLIDEAN) hipLaunchKernelGGL(shift_threshold_kernel<1>, grid, block, 0, st, ctls, n_queries, dim, thr);
+    else hipLaunchKernelGGL(shift_threshold_kernel<2>, grid, block, 0, st, ctls, n_queries, dim, thr);
+}
+
+// Which of the two forms serves a batch. The query-stationary form (trag_qstat.hip) reads the
+// corpus once for up to 2048 queries, and wins where its workgroups are full: rows of up to 384
+// components and more than 128 queries (measured on 1.25 M x 384: 0.49 against 0.51 ms at 256
+// queries from the mirror, 0.55 against 0.66 from the f32 rows, 1.46 / 1.65 against 1.90 / 2.41 ms
+// at 1000). Smaller batches would pad its 256-query groups, and longer rows leave its waves too
+// few registers (built for 768 components it ran 1 M x 768 x 256 in 1.15 / 0.89 ms against the
+// tiled kernels' 0.98 / 0.76): the tiled kernels of this file serve those, 256 queries a pass.
+// TRAG_BF16_TILED=1 forces the tiled kernels everywhere, for comparison.
+bool bf16_uses_qs(uint32_t dim, uint32_t metric, uint32_t n_queries) {
+    static int tiled = -1;
+    if (tiled < 0) {
+        const char* t = getenv("TRAG_BF16_TILED");
+        tiled = (t && t[0] == '1') ? 1 : 0;
+    }
+    return !tiled && qs_supports(dim, metric) && n_queries > 128;
+}
+
+uint32_t bf16_max_batch(uint32_t dim, uint32_t metric, uint32_t n_queries) {
+    return bf16_uses_qs(dim, metric, n_queries) ? qs_max_batch(dim) : BATCH_QUERIES;
+}
+
 // d_mirror != nullptr: the passes read the bf16 mirror instead of the f32 corpus.
 hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
                             const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
                             const float* d_vmax_sq, hipStream_t st) {
     hipError_t e = launch_batch_prep(d_Q, n_queries, a.dim, s.ctls, need, k, d_vmax_sq, st);
     if (e != hipSuccess) return e;
+    if (bf16_uses_qs(a.dim, a.metric, n_queries)) return launch_qs_scan(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
     if (d_mirror) {
         if (a.metric == TRAG_COSINE) bf16_scan_metric<0, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
         else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);

@@ -181,6 +181,16 @@ hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs
                             const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
                             const float* d_vmax_sq, hipStream_t st);
 double bf16_list_estimate(uint64_t n_rows, uint32_t need, uint32_t dim);
+// most queries one launch_bf16_scan / launch_bf16_finish pair takes at this dimension
+uint32_t bf16_max_batch(uint32_t dim, uint32_t metric, uint32_t n_queries);
+bool bf16_uses_qs(uint32_t dim, uint32_t metric, uint32_t n_queries);
+// query-stationary form of the prefilter (trag_qstat.hip)
+bool qs_supports(uint32_t dim, uint32_t metric);
+uint32_t qs_group_queries(uint32_t dim);
+uint32_t qs_max_batch(uint32_t dim);
+uint32_t qs_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim);
+hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+                          const float* d_norm2, const Bf16Scratch& s, uint32_t need, hipStream_t st);
 // bf16 mirror of the corpus (trag_mirror.hip) and the stages after its scan (trag_kernels.hip)
 hipError_t launch_to_bf16(const float* d_src, uint64_t n_floats, uint16_t* d_dst, hipStream_t st);
 bool mirror_scan_supports_dim(uint32_t dim);

@@ -1,0 +1,636 @@
+// Query batches, bf16 matrix-core prefilter, QUERY-STATIONARY form.
+//
+// Q x D^T with N ~ 10^6 corpus rows, B <= 2048 queries and K = d <= 384 is not a square GEMM:
+// the corpus is the only large operand and must be read ONCE per batch, whatever B is. So the
+// queries stay put and the corpus streams:
+//   * a workgroup owns 32 NW QB queries for its whole life; every wave keeps the bf16 fragments
+//     of its 32 QB queries over the full K extent in registers (QB d / 4 VGPRs per lane);
+//   * the corpus flows through LDS in tiles of RT rows x the whole K extent: all waves of the
+//     workgroup load a tile's rows with coalesced 16-byte loads (a step ahead, in registers),
+//     convert f32 -> bf16 on the way and write a padded row-major image (two tiles alternate,
+//     one barrier per tile); each wave then multiplies its queries with every 32-row subtile:
+//     QB d / 16 v_mfma_f32_32x32x16_bf16 per subtile, no barrier and no query traffic inside;
+//   * a batch larger than one workgroup's queries is split into G query groups. The G
+//     workgroups that stream the same corpus tiles sit on one XCD (blockIdx % 8 equal), so the
+//     corpus leaves HBM once and the other G - 1 reads are hits in that XCD's L2 or in the
+//     Infinity Cache (placement is a speed matter only: nothing depends on it for correctness);
+//   * the epilogue never writes a score: MODE 1 compares each accumulator with its query's
+//     threshold (one fma and a running maximum per accumulator; the hits are appended to
+//     the query's candidate list WITH their approximate score), MODE 0 (the sample pass that
+//     finds the thresholds) keeps per-(query, 32 rows) maxima.
+// The bound, the sample / threshold logic and the exact f32 finish are those of trag_bf16.hip.
+// After the full pass qs_prune_kernel takes, per query, the need-th largest approximate score of
+// the list -- now a statistic of ALL rows, not of a sample -- and keeps only the rows within
+// 2 eps of it: the exact re-score touches tens of rows per query instead of hundreds.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+#include "trag_device.h"
+#include "trag_internal.h"
+
+namespace trag {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float max_over_32_lanes(float x) {
+    // lanes 0..31 and 32..63 separately: four DPP steps inside each row of 16, then the other row
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0xB1, 0xF, 0xF, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x4E, 0xF, 0xF, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x141, 0xF, 0xF, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x140, 0xF, 0xF, false)));
+    return fmaxf(x, __shfl_xor(x, 16));
+}
+
+// KS: k-steps of 16 (d = 16 KS). NW: waves per workgroup (8: two per SIMD, 256 registers each).
+// QB: blocks of 32 queries per wave (each fragment read from LDS then feeds QB MFMAs; 2 with one
+// wave per SIMD was measured slower than 1 with two: 1.96 against 1.41 ms on 1.25 M x 384 x 1000,
+// the second wave hides more than the halved LDS traffic gains). RT: corpus rows per LDS tile
+// (NSUB = RT / 32 subtiles). MODE 0 sample pass / 1 full pass. MIR: the corpus operand is the
+// store's bf16 mirror. DP: steps a staging load is in flight. NTL: non-temporal corpus loads.
+//
+// The unit of work is a STEP = one 32-row subtile: d / 16 k-steps per wave, their fragments read
+// through a ring of four register sets (a read is issued right behind the MFMA that frees its
+// slot and is needed four k-steps later). LDS holds 2 NSUB subtile images. During step
+// u the workgroup also stages: every few MFMAs a thread converts one of its 16-byte pieces of
+// subtile u + NSUB (loaded DP steps ago) into that subtile's image and at once issues the load of
+// the same piece DP subtiles further on -- so every load is in flight for whole steps and the
+// loads in flight never drop to zero (issuing them in one burst per step left the memory system
+// idle most of the time: 68 % of the wave cycles were spent waiting). One barrier per NSUB steps.
+// Every tile runs the same instructions -- no variant for a stream's last tiles, whose loads are
+// clamped instead -- so the loop is one basic-block chain, the staging registers need no copies
+// at its back edge, and the compiler waits for a staged piece with a counted vmcnt.
+// The test of a step's accumulators against the thresholds is spread over the k-steps of the NEXT
+// step (see test_some).
+//
+// Hits (MODE 1) go to a list in LDS first (two lists, by tile parity): appending to a query's
+// list in memory takes an atomic whose return the wave must wait for, and that wait drains every
+// load the wave has in flight. Wave 0 empties a list into memory when it holds enough, at a time
+// when nobody appends to it (the other parity's tile), and both lists at the end.
+template <int KS, int NW, int QB, int RT, int MODE, bool MIR, int DP, bool NTL>
+__global__ void __launch_bounds__(64 * NW, NW / 4)
+qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mirror,
+               const __bf16* __restrict__ Qb, const float* __restrict__ norm2,
+               const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t n_queries, uint32_t G,
+               uint32_t S, uint32_t tile_step, uint32_t metric,
+               SearchCtl* __restrict__ ctls, const float* __restrict__ thr, uint32_t* __restrict__ tmax,
+               size_t tmax_stride, uint32_t* __restrict__ cand, uint32_t* __restrict__ cvals) {
+    constexpr int D = KS * 16;
+    constexpr int NT = 64 * NW;
+    constexpr int STRIDE = D / 2 + 4;          // dwords per image row: the 4 spare dwords keep the 16-byte
+                                               // fragment reads of 16 different rows on different banks
+    constexpr int PE = MIR ? 8 : 4;            // corpus elements per 16-byte piece
+    constexpr int PPR = D / PE;                // pieces per row
+    constexpr int NSUB = RT / 32;              // subtiles per tile
+    constexpr int NSLOT = 2 * NSUB;            // subtile images in LDS
+    constexpr int NL = 32 * PPR / NT;          // pieces per thread and subtile
+    constexpr int NF = 4;                      // fragment reads in flight
+    constexpr int PER = KS / NL;               // MFMAs between two staged pieces
+    constexpr int HITS = 512, FLUSH_AT = 256;  // LDS hit list: capacity, and the fill that triggers a flush
+    // DP: subtiles whose loads are in flight (a load is issued DP steps before its piece is written)
+    constexpr int LOOK = 1 + (NSUB - 1 + DP) / NSUB;   // the furthest tile ahead a step loads from
+    static_assert(32 * PPR % NT == 0 && RT % 32 == 0 && D % 128 == 0 && KS >= NF && KS % NL == 0, "tile geometry");
+    static_assert(NSUB % DP == 0 || DP == 2 * NSUB, "ring geometry");
+    __shared__ __attribute__((aligned(16))) uint32_t img[NSLOT][32 * STRIDE];
+    __shared__ __attribute__((aligned(8))) float rowc[NSLOT][32][2];   // per row: scale, shift (see below)
+    __shared__ uint32_t hit_q[2][MODE == 1 ? HITS : 1], hit_row[2][MODE == 1 ? HITS : 1], hit_v[2][MODE == 1 ? HITS : 1];
+    __shared__ uint32_t hit_n[2];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+
+    // workgroups of one XCD: G query groups x S corpus streams
+    const uint32_t b = blockIdx.x;
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    const uint32_t g = slot % G;
+    const uint32_t strm = (slot / G) * 8u + xcd, n_streams = S * 8u;
+    // tiles of the pass: every tile_step-th of the corpus; unit e of the pass is corpus tile e * tile_step.
+    // This stream takes the units strm, strm + n_streams, ...: n_mine of them.
+    const uint32_t n_tiles = (n_rows + RT - 1) / RT;
+    const uint32_t n_units = (n_tiles + tile_step - 1) / tile_step;
+    if (strm >= n_units) return;
+    const uint32_t n_mine = (n_units - strm + n_streams - 1) / n_streams;
+    // The G workgroups of a stream walk its units in rotated order inside groups of G (group c:
+    // c G + (j + g) % G for j = 0 .. G - 1), so that at any time they ask memory for G different
+    // tiles -- G times the bytes in flight -- and each tile comes from HBM once and from L2 / the
+    // Infinity Cache for the other G - 1. A last, partial group is walked in plain order.
+    const uint32_t n_rot = (n_mine / G) * G;
+    // the units in this workgroup's order, one after the other (no division in the loop); past the
+    // last one: NO_UNIT
+    constexpr uint32_t NO_UNIT = 0xFFFFFFFFu;
+    uint32_t gen_n = 0, gen_c = 0, gen_j = 0;
+    auto next_unit = [&]() __attribute__((always_inline)) -> uint32_t {
+        uint32_t m = gen_n;
+        if (gen_n < n_rot) {
+            uint32_t jj = gen_j + g;
+            if (jj >= G) jj -= G;
+            m = gen_c + jj;
+        }
+        const bool valid = gen_n < n_mine;
+        gen_n += 1;
+        gen_j += 1;
+        if (gen_j == G) { gen_j = 0; gen_c += G; }
+        return valid ? m * n_streams + strm : NO_UNIT;
+    };
+    const uint32_t rows_per_unit = tile_step * RT;
+    const uint32_t q0 = g * (32u * NW * QB) + (uint32_t)wid * (32u * QB);   // this wave's queries: q0 .. q0 + 32 QB - 1
+
+    // Wait for every vector-memory operation of this wave (s_waitcnt vmcnt(0) only). Loads return in
+    // order, so the compiler can wait for "all but the newest N"; stores and atomics return out of
+    // order with them, and one of those possibly in flight -- even on a path that is almost never
+    // taken -- turns every later wait in the loop into a wait for ALL loads, the newest included.
+    // Each rare path that writes to memory therefore ends with this, and the staging loads of the
+    // common path keep their counted waits.
+    auto drain_vmem = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_waitcnt(0x0F70); };
+    // the queries' fragments, for the whole K extent, for the life of the workgroup
+    bf16x8 qa[QB][KS];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const __bf16* qp = Qb + (size_t)(q0 + 32u * (uint32_t)qb + (uint32_t)r) * D + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qa[qb][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + ks * 16));
+    }
+    // accumulator register rr of block qb of lane (r, h) belongs to query q0 + 32 qb + qrow(rr) and corpus
+    // row r of the subtile; e = 16 qb + rr numbers a lane's accumulators
+    auto qrow = [&](int rr) __attribute__((always_inline)) { return (uint32_t)((rr & 3) + 8 * (rr >> 2) + 4 * h); };
+    constexpr int NA = 16 * QB;
+    float th[NA];
+    if (MODE == 1) {
+#pragma unroll
+        for (int rr = 0; rr < NA; ++rr) {
+            const uint32_t q = q0 + 32u * (uint32_t)(rr >> 4) + qrow(rr & 15);
+            th[rr] = q < n_queries ? thr[q] : INFINITY;
+            // A query outside the bound's range (threshold -inf) would list every row: its list is
+            // marked as overflowed once, here, and it takes no further part (the final stage reports
+            // the overflow and the host repeats the query with the exact scan).
+            if (th[rr] == -INFINITY) {
+                if (strm == 0u && r == 0) atomicMax(&ctls[q].cand_count, CAND_CAP + 1u);
+                th[rr] = INFINITY;
+            }
+        }
+        if (tid < 2) hit_n[tid] = 0u;
+        drain_vmem();
+    }
+
+    // staging: the 32 rows of a subtile are one contiguous block of memory, cut into 16-byte pieces;
+    // piece i * NT + tid is this thread's i-th (consecutive lanes, consecutive pieces: coalesced)
+    uint32_t loff[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int p = i * NT + tid, row = p / PPR, c = p % PPR;
+        loff[i] = (uint32_t)(row * STRIDE + c * (MIR ? 4 : 2));
+    }
+    u32x4 pre[DP][NL];
+    // every thread also carries the norm and the tombstone word of row (tid & 31) of the staged
+    // subtile (32 threads would do; all of them doing the same keeps the step free of branches,
+    // which is what lets the compiler count the loads in flight instead of draining them)
+    float pre_nb2[DP];
+    uint32_t pre_dead[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) { pre_nb2[k] = 0.0f; pre_dead[k] = 0u; }
+    // load piece i of the subtile that starts at row0 into slot k of the staging registers. The
+    // subtile is one contiguous block of 32 PPR pieces; a piece past the corpus' end (a partial last
+    // tile, or a tile of a unit past the stream's last) reads the corpus' last piece instead: its row
+    // counts as removed, whatever it holds. No branch: the same instructions run for every tile,
+    // which keeps the loop a single body whose loads the compiler can count.
+    const uint64_t last_piece = (uint64_t)n_rows * (uint64_t)PPR - 1u;
+    const u32x4* const src = MIR ? reinterpret_cast<const u32x4*>(mirror) : reinterpret_cast<const u32x4*>(corpus);
+    auto issue_piece = [&](int k, int i, uint32_t row0) __attribute__((always_inline)) {
+        uint64_t gp = (uint64_t)row0 * (uint64_t)PPR + (uint64_t)(uint32_t)(i * NT + tid);
+        gp = gp < last_piece ? gp : last_piece;
+        pre[k][i] = NTL ? __builtin_nontemporal_load(src + gp) : src[gp];
+        if (i == 0) {
+            uint32_t row = row0 + (uint32_t)(tid & 31);
+            row = row < n_rows - 1u ? row : n_rows - 1u;
+            uint32_t word = row >> 5;
+            asm volatile("" : "+v"(word));   // (a vector load: as a scalar load it would share the LDS counter
+                                              // and drain the fragment ring once per step)
+            pre_dead[k] = dead[word];
+            pre_nb2[k] = norm2[row];
+        }
+    };
+    // v = the row-dependent part of the score = fma(dot, scale, shift): cosine dot / ||v||, dot
+    // product dot, Euclidean 2 dot - ||v||^2. Rows that take no part (removed, past the end):
+    // scale 0, shift -inf. Rows whose norm is outside the bound's range must always be
+    // candidates: scale 0, shift +inf (the sample pass leaves them out). The reciprocal square
+    // root is the hardware's (1 ulp): v only has to be within the bound's 1 % slack of its value.
+    auto write_piece = [&](int k, int i, int sl, uint32_t row0) __attribute__((always_inline)) {
+        if (MIR) {
+            *reinterpret_cast<u32x4*>(&img[sl][loff[i]]) = pre[k][i];
+        } else {
+            const bf16x4 hv = __builtin_convertvector(__builtin_bit_cast(v4f, pre[k][i]), bf16x4);
+            *reinterpret_cast<u32x2*>(&img[sl][loff[i]]) = __builtin_bit_cast(u32x2, hv);
+        }
+        if (i == 0) {
+            const uint32_t row = row0 + (uint32_t)(tid & 31);
+            const float nb2 = metric == 2u ? 1.0f : pre_nb2[k];
+            const bool live = row < n_rows && !((pre_dead[k] >> (row & 31u)) & 1u);
+            const bool forced = !(nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY));
+            float sc = metric == 0u ? (nb2 > 0.0f ? __builtin_amdgcn_rsqf(nb2) : 0.0f) : (metric == 1u ? 2.0f : 1.0f);
+            float sh = metric == 1u ? -nb2 : 0.0f;
+            sc = forced ? 0.0f : sc;
+            sh = forced ? INFINITY : sh;
+            sc = live ? sc : 0.0f;
+            sh = live ? sh : -INFINITY;
+            float2 v2 = make_float2(sc, sh);
+            *reinterpret_cast<float2*>(&rowc[sl][tid & 31][0]) = v2;   // (16 threads store the same pair: harmless)
+        }
+    };
+
+    bf16x8 fr[NF];     // the fragment ring
+    auto frag = [&](int sl, int ks) __attribute__((always_inline)) {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&img[sl][r * STRIDE + 4 * h + ks * 8]));
+    };
+    // one hit: query q, corpus row, approximate value v -> this tile parity's LDS list. A list that
+    // is full (a burst: hundreds of hits inside one tile) marks the query's list in memory as
+    // overflowed instead: the host repeats that query exactly.
+    auto append = [&](int par, uint32_t q, uint32_t row, float v) __attribute__((always_inline)) {
+        const uint32_t pos = atomicAdd(&hit_n[par], 1u);
+        if (pos < (uint32_t)HITS) {
+            hit_q[par][pos] = q;
+            hit_row[par][pos] = row;
+            hit_v[par][pos] = __float_as_uint(v);
+        } else {
+            atomicMax(&ctls[q].cand_count, CAND_CAP + 1u);
+            drain_vmem();
+        }
+    };
+    // wave 0 only, while no wave appends to list `par`
+    auto flush = [&](int par) __attribute__((always_inline)) {
+        const uint32_t n = min(hit_n[par], (uint32_t)HITS);
+        for (uint32_t i = (uint32_t)lane; i < n; i += 64u) {
+            const uint32_t q = hit_q[par][i];
+            const uint32_t gp = atomicAdd(&ctls[q].cand_count, 1u);
+            if (gp < CAND_CAP) {
+                cand[(size_t)q * CAND_CAP + gp] = hit_row[par][i];
+                cvals[(size_t)q * CAND_CAP + gp] = hit_v[par][i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) hit_n[par] = 0u;
+        drain_vmem();
+    };
+    // MODE 0: the largest value of each (query, subtile), as an ordered key
+    auto epilogue = [&](const v16f (&acc)[QB], int sl, uint32_t idx) __attribute__((always_inline)) {
+        const float2 rc = *reinterpret_cast<const float2*>(&rowc[sl][r][0]);
+        float sc = rc.x, sh = rc.y;
+        {
+            if (sh == INFINITY) { sc = 0.0f; sh = -INFINITY; }
+            // (the query index passes through an opaque move: the output addresses are then
+            // formed here, not hoisted out of the step loop into registers for its whole length)
+            uint32_t qb = q0 + 4u * (uint32_t)h;
+            asm volatile("" : "+v"(qb));
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                const int rr = e & 15;
+                const float best = max_over_32_lanes(__builtin_fmaf(acc[e >> 4][rr], sc, sh));
+                const uint32_t q = qb + (uint32_t)(32 * (e >> 4) + (rr & 3) + 8 * (rr >> 2));
+                if (r == 0 && q < n_queries)
+                    tmax[q * tmax_stride + idx] = (best > -INFINITY && best < INFINITY) ? score_key(best) : 0u;
+            }
+        }
+    };
+    // MODE 1. Whether lane (r, h) has a hit among its sixteen accumulators: the value of accumulator
+    // rr is v = fma(acc, sc, sh) and a hit is v >= th[rr]; sh is the same for all sixteen (one corpus
+    // row per lane), so the test is  max over rr of fma(acc[rr], sc, -th[rr])  + sh >= 0: two
+    // operations per accumulator, whatever the metric. (For the Euclidean metric this sum is rounded
+    // in another order than v - th: a difference of a few units in the last place, against a
+    // threshold that keeps 1 % of the bound as slack.) These operations do not wait for a step's end:
+    // the accumulators of step u are tested, a few at a time, BETWEEN the MFMAs of step u + 1, where
+    // the vector ALU is idle anyway; done after the step they would stall the matrix pipe of both
+    // waves of the SIMD, which reach their step ends together.
+    auto test_some = [&](const v16f (&acc)[QB], float sc, int first, int count, float m) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = first; e < first + count && e < NA; ++e)
+            m = fmaxf(m, __builtin_fmaf(acc[e >> 4][e & 15], sc, -th[e]));   // (fmaxf drops a NaN operand)
+        return m;
+    };
+    // ... and the rare continuation: list the hits of a lane whose test did not fail (a NaN counts
+    // as a hit; a row that takes no part, scale 0 and shift -inf, has none).
+    auto list_hits = [&](const v16f (&acc)[QB], float sc, float sh, float m, uint32_t row0, int par) __attribute__((always_inline)) {
+        const bool maybe = !(m + sh < 0.0f);
+        if (maybe) {
+            const uint32_t row = row0 + (uint32_t)r;
+            const bool live = sh != -INFINITY || sc != 0.0f;
+            // (opaque move: without it the list addresses of the sixteen queries are hoisted
+            // out of the step loop and held in registers the fragment reads need)
+            uint32_t qb = q0 + 4u * (uint32_t)h;
+            asm volatile("" : "+v"(qb));
+#pragma unroll
+            for (int e = 0; e < NA; ++e) {
+                const int rr = e & 15;
+                const float a = acc[e >> 4][rr];
+                const float v = __builtin_fmaf(a, sc, sh);
+                const uint32_t q = qb + (uint32_t)(32 * (e >> 4) + (rr & 3) + 8 * (rr >> 2));
+                if (!(__builtin_fmaf(a, sc, -th[e]) + sh < 0.0f) && live && q < n_queries) append(par, q, row, v);
+            }
+        }
+    };
+
+    // prologue: the first NSUB subtiles into their images, the next DP into the staging registers.
+    // A unit past the stream's last is loaded like any other (from row 0: its data is never used).
+    uint32_t unit[LOOK + 1];   // tiles n .. n + LOOK
+#pragma unroll
+    for (int t = 0; t <= LOOK; ++t) {
+        const uint32_t u = next_unit();
+        unit[t] = u == NO_UNIT ? 0u : u;
+    }
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        const uint32_t row0 = unit[0] * rows_per_unit + 32u * (uint32_t)sub;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) issue_piece(0, i, row0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) write_piece(0, i, sub, row0);
+    }
+#pragma unroll
+    for (int w = NSUB; w < NSUB + DP; ++w) {   // subtile w of the stream: tile w / NSUB, ring slot w % DP
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            issue_piece(w % DP, i, unit[w / NSUB] * rows_per_unit + 32u * (uint32_t)(w % NSUB));
+    }
+    __syncthreads();
+
+    // One tile = NSUB steps + the barrier. Step `sub` of tile n is step u = n NSUB + sub of the stream:
+    // the workgroup writes subtile u + NSUB (subtile `sub` of tile n + 1) from ring slot
+    // (u + NSUB) % DP and loads subtile u + NSUB + DP into the same slot. ODD: parity of tile n + 1
+    // (only matters when the ring spans two tiles).
+    // MODE 1: the step before this one, whose accumulators are still to be tested (at the start: none:
+    // a row that takes no part)
+    v16f accp[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accp[qb][e] = 0.0f;
+    float scp = 0.0f, shp = -INFINITY, mp = -INFINITY;
+    uint32_t row0p = 0u;
+    constexpr int NCH = KS < 16 ? KS : 16;       // k-steps of a step that are followed by a piece of the test
+    constexpr int CH = (NA + NCH - 1) / NCH;     // accumulators per piece
+    auto run_tile = [&](auto odd_tag, uint32_t n) __attribute__((always_inline)) {
+        constexpr int ODD = decltype(odd_tag)::value ? 1 : 0;
+        const int half = (int)(n & 1u);   // which half of the images this tile's subtiles are in; its hit list
+        if (MODE == 1 && wid == 0 && hit_n[half ^ 1] >= (uint32_t)FLUSH_AT) flush(half ^ 1);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) fr[j] = frag(half * NSUB, j);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const int sl = half * NSUB + sub;            // image of this step
+            const int wsl = (half ^ 1) * NSUB + sub;     // image written during this step
+            const int ring = (ODD * NSUB + sub) % DP;    // (a constant after unrolling)
+            const int it = 1 + (sub + DP) / NSUB, isub = (sub + DP) % NSUB;   // tile ahead / subtile of the load
+            const uint32_t row0 = unit[0] * rows_per_unit + 32u * (uint32_t)sub;
+            const uint32_t row0_write = unit[1] * rows_per_unit + 32u * (uint32_t)sub;
+            const uint32_t row0_issue = unit[it] * rows_per_unit + 32u * (uint32_t)isub;
+            v16f acc[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[qb][e] = 0.0f;
+            auto k_step = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[qb][ks], fr[ks % NF], acc[qb], 0, 0, 0);
+                if (ks + NF < KS) fr[ks % NF] = frag(sl, ks + NF);
+                if (ks % PER == PER - 1) {
+                    write_piece(ring, ks / PER, wsl, row0_write);
+                    issue_piece(ring, ks / PER, row0_issue);
+                }
+            };
+            // (two loops, so that the listing of hits is not part of a loop body: with it inside, the
+            // body times its trip count passes the size up to which the compiler unrolls fully, and the
+            // fragment registers end up indexed at run time, in memory)
+#pragma unroll
+            for (int ks = 0; ks < (MODE == 1 ? NCH : 0); ++ks) {
+                k_step(ks);
+                mp = test_some(accp, scp, ks * CH, CH, mp);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MODE == 1) list_hits(accp, scp, shp, mp, row0p, half);
+#pragma unroll
+            for (int ks = (MODE == 1 ? NCH : 0); ks < KS; ++ks) {
+                k_step(ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (sub + 1 < NSUB) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j) fr[(KS + j) % NF] = frag(sl + 1, j);
+            }
+            if (MODE == 0) {
+                epilogue(acc, sl, unit[0] * (uint32_t)NSUB + (uint32_t)sub);   // (index among the sampled subtiles)
+            } else {
+                const float2 rc = *reinterpret_cast<const float2*>(&rowc[sl][r][0]);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) accp[qb] = acc[qb];
+                scp = rc.x;
+                shp = rc.y;
+                mp = -INFINITY;
+                row0p = row0;
+            }
+        }
+        __syncthreads();
+    };
+    constexpr bool BY_PARITY = DP > NSUB;
+    for (uint32_t n = 0; n < n_mine; ++n) {
+        if (BY_PARITY && ((n + 1u) & 1u)) run_tile(std::integral_constant<bool, true>{}, n);
+        else run_tile(std::integral_constant<bool, false>{}, n);
+#pragma unroll
+        for (int t = 0; t < LOOK; ++t) unit[t] = unit[t + 1];
+        const uint32_t u = next_unit();
+        unit[LOOK] = u == NO_UNIT ? 0u : u;
+    }
+    if (MODE == 1) {
+        // the last step's accumulators; then, when every wave has listed its hits, both lists
+        mp = test_some(accp, scp, 0, NA, mp);
+        list_hits(accp, scp, shp, mp, row0p, 0);
+        __syncthreads();
+        if (wid == 0) {
+            flush(0);
+            flush(1);
+        }
+    }
+}
+
+// Per query, after the full pass: the candidate list holds every row whose approximate score v
+// reaches the sample's threshold, with v. A = the need-th largest finite v of the list: `need`
+// rows reach A approximately, so the exact need-th best is >= A - eps and every row of the exact
+// top `need` has v >= A - 2 eps. Keep those rows (and the rows whose v is +inf or NaN: rows
+// outside the bound's range, always scored exactly), drop the rest, and record the lowered
+// threshold for the final check. A list that overflowed is left alone (the final stage reports it).
+template <int METRIC>
+__global__ void __launch_bounds__(1024)
+qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const uint32_t* __restrict__ cvals,
+                float* __restrict__ thr, uint32_t d) {
+    __shared__ unsigned long long sk[CAND_CAP];
+    __shared__ uint32_t rows[CAND_CAP];
+    __shared__ uint32_t n_inf_sh, keep_sh;
+    const int tid = threadIdx.x;
+    const uint32_t y = blockIdx.x;
+    SearchCtl* ctl = ctls + y;
+    const uint32_t C = ctl->cand_count;
+    const uint32_t need = ctl->need;
+    if (C > CAND_CAP || C <= need) return;
+    uint32_t* cq = cand + (size_t)y * CAND_CAP;
+    const uint32_t* vq = cvals + (size_t)y * CAND_CAP;
+    uint32_t P = 64;
+    while (P < C) P <<= 1;
+    if (tid == 0) { n_inf_sh = 0; keep_sh = 0; }
+    __syncthreads();
+    uint32_t n_inf = 0;
+    for (uint32_t i = tid; i < P; i += 1024u) {
+        unsigned long long e = 0ull;
+        if (i < C) {
+            const float v = __uint_as_float(vq[i]);
+            rows[i] = cq[i];
+            // +inf and NaN sort first: they are kept whatever the threshold
+            const uint32_t key = (v != v || v == INFINITY) ? 0xFFFFFFFFu : score_key(v);
+            n_inf += key == 0xFFFFFFFFu;
+            e = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+        }
+        sk[i] = e;
+    }
+    if (n_inf) atomicAdd(&n_inf_sh, n_inf);
+    for (uint32_t size = 2; size <= P; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < P / 2; i += 1024u) {
+                const uint32_t pos = 2 * i - (i & (stride - 1));
+                const unsigned long long a = sk[pos], b = sk[pos + stride];
+                const bool desc = (pos & size) == 0;
+                if (desc ? (a < b) : (a > b)) { sk[pos] = b; sk[pos + stride] = a; }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t F = n_inf_sh;
+    if (F + need > C) return;   // fewer than `need` rows with a usable score: keep the whole list
+    const float A = key_score((uint32_t)(sk[F + need - 1] >> 32));
+    // the lowered threshold, in score space (t, for the final check) and in v space (tv)
+    const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
+    const float eps = bf16_eps<METRIC>(d, na, vmax);
+    float t, tv;
+    if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
+    else if (METRIC == 1) { t = (A - ctl->na_sq) - 2.02f * eps; tv = t + ctl->na_sq; }
+    else { t = A - 2.02f * eps; tv = t; }
+    if (!(t == t) || !(tv == tv) || !(tv > thr[y])) return;   // nothing gained (or out of range): keep the list
+    const uint32_t tkey = score_key(tv);
+    // the survivors are a prefix of the sorted list
+    uint32_t mine = 0;
+    for (uint32_t i = tid; i < C; i += 1024u) mine += (uint32_t)(sk[i] >> 32) >= tkey;
+    if (mine) atomicAdd(&keep_sh, mine);
+    __syncthreads();
+    const uint32_t keep = keep_sh;
+    for (uint32_t i = tid; i < keep; i += 1024u)
+        cq[i] = rows[0xFFFFFFFFu - (uint32_t)(sk[i] & 0xFFFFFFFFull)];
+    if (tid == 0) {
+        ctl->cand_count = keep;
+        ctl->t_key = score_key(t);
+        thr[y] = tv;
+    }
+}
+
+bool qs_supports(uint32_t dim, uint32_t metric) {
+    return metric <= TRAG_DOT_PRODUCT && (dim == 128 || dim == 256 || dim == 384);
+}
+
+uint32_t qs_group_queries(uint32_t) { return 256u; }
+
+// Most queries one pass takes: 8 query groups (the streams per XCD shrink with the groups).
+uint32_t qs_max_batch(uint32_t dim) { return 8u * qs_group_queries(dim); }
+
+// Rows per LDS tile for this dimension (the granularity of the sample pass).
+uint32_t qs_tile_rows(uint32_t) { return 64u; }
+
+template <int KS, int NW, int QB, int RT, int MODE, bool MIR, int DP, bool NTL>
+static void qs_launch_tile(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
+                          const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
+    static int cu_per_xcd = 0;
+    if (cu_per_xcd == 0) {
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        cu_per_xcd = std::max(1, n_cu / 8);
+    }
+    const uint32_t QW = 32u * NW * QB;
+    const uint32_t G = (n_queries + QW - 1) / QW;
+    const uint32_t S = std::max<uint32_t>(1u, (uint32_t)cu_per_xcd / G);
+    const uint32_t grid = 8u * S * G;
+    hipLaunchKernelGGL((qs_gemm_kernel<KS, NW, QB, RT, MODE, MIR, DP, NTL>), dim3(grid), dim3(64 * NW), 0, st, a.corpus,
+                       d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, n_queries, G, S,
+                       tile_step, a.metric, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys);
+}
+
+// The corpus is read by G workgroups of one XCD: keep it in L2 for them; a single reader (one
+// query group) streams past the caches with non-temporal loads.
+template <int KS, int NW, int QB, int RT, int MODE, bool MIR, int DP>
+static void qs_launch_one(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
+                          const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
+    if (n_queries <= 32u * NW * QB) qs_launch_tile<KS, NW, QB, RT, MODE, MIR, DP, true>(n_queries, a, d_mirror, d_norm2, s, tile_step, st);
+    else qs_launch_tile<KS, NW, QB, RT, MODE, MIR, DP, false>(n_queries, a, d_mirror, d_norm2, s, tile_step, st);
+}
+
+#ifndef QS_DP_A
+#define QS_DP_A 1
+#endif
+template <int MODE, bool MIR>
+static void qs_launch(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
+                      const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
+    switch (a.dim) {
+    case 128: qs_launch_one<8, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, st); break;
+    case 256: qs_launch_one<16, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, st); break;
+    case 384: qs_launch_one<24, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, st); break;
+    default: break;   // (qs_supports: the caller never comes here with another dimension)
+    }
+}
+
+// Tiles between two sampled tiles. As bf16_sample_step, but the lists may be longer (the prune
+// stage shortens them before anything is re-scored): expected length need * step * w <= 1024.
+uint32_t qs_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
+    const uint64_t n_sub = (n_rows + 31) / 32;
+    if (need == 0) need = 1;
+    uint64_t step = n_sub / (64ull * need);   // the sample must hold many more 32-row groups than rows wanted
+    const double fd = (double)dim;
+    const double eps = 0.0078125 * 1.003 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
+    const double w = std::exp(10.0 * eps * std::sqrt(fd));
+    const double by_list = 1024.0 / ((double)need * w);
+    if ((double)step > by_list) step = (uint64_t)by_list;
+    return (uint32_t)(step < 1 ? 1 : (step > 16 ? 16 : step));
+}
+
+// declared in trag_bf16.hip
+void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padded, uint32_t dim, uint16_t* qb,
+                            hipStream_t st);
+void launch_shift_threshold(uint32_t metric, SearchCtl* ctls, uint32_t n_queries, uint32_t dim, float* thr,
+                            hipStream_t st);
+
+// The whole prefilter for up to qs_max_batch(dim) queries: sample pass, thresholds, full pass, prune.
+// The caller has run launch_batch_prep (norms, control blocks).
+hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+                          const float* d_norm2, const Bf16Scratch& s, uint32_t need, hipStream_t st) {
+    const uint32_t QW = qs_group_queries(a.dim);
+    const uint32_t padded = (n_queries + QW - 1) / QW * QW;
+    launch_queries_to_bf16(d_Q, n_queries, padded, a.dim, s.qb, st);
+    const uint32_t step = qs_sample_step(a.n_rows, need, a.dim);
+    const uint32_t RT = qs_tile_rows(a.dim);
+    if (d_mirror) qs_launch<0, true>(n_queries, a, d_mirror, d_norm2, s, step, st);
+    else qs_launch<0, false>(n_queries, a, d_mirror, d_norm2, s, step, st);
+    const uint32_t n_tiles = (a.n_rows + RT - 1) / RT;
+    const uint32_t sampled = (n_tiles + step - 1) / step;
+    launch_tau_select(s.tmax, s.tmax_stride, sampled * (RT / 32), s.ctls, n_queries, st);
+    launch_shift_threshold(a.metric, s.ctls, n_queries, a.dim, s.thr, st);
+    if (d_mirror) qs_launch<1, true>(n_queries, a, d_mirror, d_norm2, s, 1, st);
+    else qs_launch<1, false>(n_queries, a, d_mirror, d_norm2, s, 1, st);
+    if (a.metric == TRAG_COSINE)
+        hipLaunchKernelGGL(qs_prune_kernel<0>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, a.dim);
+    else if (a.metric == TRAG_EUCLIDEAN)
+        hipLaunchKernelGGL(qs_prune_kernel<1>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, a.dim);
+    else
+        hipLaunchKernelGGL(qs_prune_kernel<2>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, a.dim);
+    return hipGetLastError();
+}
+
+}  // namespace trag
