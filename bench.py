@@ -316,12 +316,9 @@ def main():
         from_mirror = args.mirror and mode_used in (4, 5)
         algo_bytes = float(n_local) * d * (2.0 if from_mirror else 4.0)
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
-        if mode_used in (3, 4):     # scan launches per step
-            passes = (B + 255) // 256
-        elif mode_used == 5:
-            passes = B
-        else:
-            passes = (B + 7) // 8
+        # corpus passes per step, from the library's own count of timed scans (the bf16 prefilter
+        # takes up to 2048 queries a pass in its query-stationary form and 256 in its tiled form)
+        passes = max(1, round(scan_launches / max(args.steps, 1)))
         b_launch = B / passes                                   # queries served by one scan launch
         flops = 2.0 * b_launch * n_local * d
         tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
