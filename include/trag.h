@@ -86,6 +86,10 @@ typedef struct trag_config {
 /* VectorStore::new / with_dimension, src/index.rs:335-350 */
 trag_status trag_store_create(const trag_config *cfg, trag_store **out);
 void trag_store_destroy(trag_store *s);
+/* #[derive(Clone)] of VectorStore, src/index.rs:322: a second, independent store on the same
+ * device with the same rows (removed rows stay removed, row indices are kept), configuration and
+ * bf16 mirror setting. A device-to-device copy; scratch and learned plans are not copied. */
+trag_status trag_store_clone(trag_store *src, trag_store **out);
 
 /* VectorStore::config, src/index.rs:354-356 */
 trag_status trag_store_config(const trag_store *s, trag_config *out);

@@ -159,6 +159,53 @@ int main() {
         auto res = hr.retrieve("beta decay", 3);
         EXPECT(res.size() == 3 && res[0].chunk.id == cs[1].id && res[0].sparse_score.has_value());
     }
+    {   // insert_batch: one call for the new rows; a known id is overwritten, a repeated id keeps its last row
+        VectorStore s = VectorStore::with_dimension(2);
+        Chunk old = chunk_with("old", {1.0f, 0.0f});
+        ChunkId oid = old.id;
+        s.insert(old);
+        Chunk again("old again");
+        again.id = oid;
+        again = std::move(again).with_embedding({0.0f, 1.0f});
+        Chunk n1 = chunk_with("n1", {1.0f, 0.0f}), n2 = chunk_with("n2", {0.6f, 0.8f});
+        Chunk n1b("n1 later");
+        n1b.id = n1.id;
+        n1b = std::move(n1b).with_embedding({-1.0f, 0.0f});
+        ChunkId i1 = n1.id, i2 = n2.id;
+        s.insert_batch({n1, again, n2, n1b});
+        EXPECT(s.len() == 3);
+        auto r = s.search({0.0f, 1.0f}, 1u << 30);       // any k: the reference truncates
+        EXPECT(r.size() == 3 && r[0].first == oid && r[1].first == i2 && r[2].first == i1);
+        EXPECT(s.get(i1)->content == "n1 later" && s.get(oid)->content == "old again");
+        try { s.insert_batch({chunk_with("ok", {1.0f, 1.0f}), Chunk("no embedding")}); EXPECT(false); }
+        catch (const InvalidConfig&) {}
+        EXPECT(s.len() == 3);                            // nothing of a failed batch is inserted
+    }
+    {   // clone: same answers, independent afterwards (#[derive(Clone)], src/index.rs:322)
+        VectorStore s = VectorStore::with_dimension(2);
+        Chunk a = chunk_with("a", {1.0f, 0.0f}), b = chunk_with("b", {0.0f, 1.0f}), c = chunk_with("c", {0.6f, 0.8f});
+        s.insert_batch({a, b, c});
+        s.remove(b.id);
+        VectorStore t = s.clone();
+        EXPECT(t.len() == 2 && t.get(a.id) != nullptr && t.get(b.id) == nullptr);
+        auto rs = s.search({0.0f, 1.0f}, 5), rt = t.search({0.0f, 1.0f}, 5);
+        EXPECT(rs.size() == 2 && rt.size() == 2 && rs[0].first == c.id && rt[0].first == c.id && rs[0].second == rt[0].second);
+        t.insert(chunk_with("d", {0.0f, 1.0f}));
+        s.remove(c.id);
+        EXPECT(s.len() == 1 && t.len() == 3 && t.search({0.0f, 1.0f}, 1)[0].second == 1.0f);
+        EXPECT(s.search({0.0f, 1.0f}, 5).size() == 1);
+    }
+    {   // BM25: re-adding an id replaces its document; any k
+        BM25Index ix;
+        Chunk c("solar panels on the roof"), other("wind turbines at sea");
+        ix.add(c); ix.add(other);
+        Chunk c2("tidal power stations");
+        c2.id = c.id;
+        ix.add(c2);
+        EXPECT(ix.len() == 2 && ix.search("solar", 10).empty());
+        auto r = ix.search("tidal power", 1u << 30);
+        EXPECT(r.size() == 1 && r[0].first == c.id);
+    }
     std::printf(failures ? "%d failure(s)\n" : "host mirror: all checks passed\n", failures);
     return failures ? 1 : 0;
 }

@@ -149,3 +149,35 @@ def test_chunk_by_chunk_ingest_does_not_wait_for_the_gpu(trag, oracle):
         assert_same_ranking(r, s, er, es, "mirror scan after interleaved ingest")
     store.close()
     assert elapsed < 2.0, f"100k single-row inserts took {elapsed:.2f} s"
+
+
+def test_clone_is_an_independent_copy(trag, oracle):
+    """`#[derive(Clone)]` of the reference's store (src/index.rs:322): a clone answers like its
+    source (rows, removed rows, mirror setting, deferred single-row inserts included) and the two
+    diverge freely afterwards."""
+    rng = np.random.default_rng(5)
+    n, d = 5000, 64
+    corpus = rng.standard_normal((n, d)).astype(np.float32)
+    store = trag.VectorStore.with_dimension(d)
+    store.insert_rows(corpus[:-3])
+    for r in corpus[-3:]:
+        store.insert_rows(r[None, :])            # small inserts: finished by the next search -- or by clone
+    store.set_bf16_mirror(True)
+    dead = np.zeros(n, dtype=np.uint8)
+    for r in (0, 77, n - 1):
+        store.remove_row(r)
+        dead[r] = 1
+    twin = store.clone()
+    assert "len=%d" % (n - 3) in repr(twin) and twin.len() == n - 3
+    assert twin.read_rows(0, n).tobytes() == corpus.tobytes()
+    q = rng.standard_normal(d).astype(np.float32)
+    er, es = oracle.search(corpus, q, 10, 0, dead=dead)
+    for s in (store, twin):
+        rows, scores = s.search_rows(q, 10)
+        assert np.array_equal(rows, er) and scores.tobytes() == es.tobytes()
+    twin.remove_row(int(er[0]))
+    twin.insert_rows(q[None, :])
+    rows, scores = twin.search_rows(q, 2)
+    assert rows[0] == n and rows[1] == er[1]
+    rows, scores = store.search_rows(q, 10)      # the source never saw any of that
+    assert np.array_equal(rows, er) and store.len() == n - 3 and twin.len() == n - 3

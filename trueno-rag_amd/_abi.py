@@ -61,6 +61,7 @@ _H = C.c_void_p
 SIGNATURES = {
     "trag_store_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "trag_store_destroy": (None, [_H]),
+    "trag_store_clone": (C.c_int, [_H, C.POINTER(_H)]),
     "trag_store_config": (C.c_int, [_H, C.POINTER(Config)]),
     "trag_store_insert": (C.c_int, [_H, _fp, C.c_uint64, C.c_uint32, _u32p]),
     "trag_store_overwrite": (C.c_int, [_H, C.c_uint32, _fp, C.c_uint32]),

@@ -1222,6 +1222,58 @@ trag_status trag_store_set_bf16_mirror(trag_store* s, int enabled) {
 
 int trag_store_has_bf16_mirror(const trag_store* s) { return s && s->d_mirror ? 1 : 0; }
 
+trag_status trag_store_clone(trag_store* src, trag_store** out) {
+    if (!src || !out) return fail(TRAG_INVALID_ARG, "null argument");
+    *out = nullptr;
+    trag_config cfg;
+    uint64_t n_rows = 0;
+    {
+        std::lock_guard<std::mutex> lk(src->mu);
+        cfg = src->cfg;
+        n_rows = src->n_rows;
+    }
+    cfg.reserve_rows = n_rows;
+    trag_store* dst = nullptr;
+    trag_status ts = trag_store_create(&cfg, &dst);
+    if (ts != TRAG_OK) return ts;
+    std::lock_guard<std::mutex> lk(src->mu);
+    DeviceGuard guard(src->device);
+    auto give_up = [&](trag_status code) { trag_store_destroy(dst); return code; };
+    if (src->n_rows > dst->cap_rows) {   // rows arrived between the two locks
+        ts = grow_rows(dst, src->n_rows);
+        if (ts != TRAG_OK) return give_up(ts);
+    }
+    ts = finish_inserts(src);            // norms of rows that small inserts appended
+    if (ts != TRAG_OK) return give_up(ts);
+    const uint64_t n = src->n_rows;
+    hipError_t e = hipStreamSynchronize(src->stream);
+    if (e == hipSuccess && src->has_last && src->last_stream != src->stream) e = hipDeviceSynchronize();
+    if (e == hipSuccess && n) {
+        const size_t dim = src->cfg.dim;
+        e = hipMemcpyAsync(dst->d_rows, src->d_rows, n * dim * sizeof(float), hipMemcpyDeviceToDevice, dst->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dst->d_norm2, src->d_norm2, n * sizeof(float), hipMemcpyDeviceToDevice, dst->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dst->d_dead, src->d_dead, ((n + 31) / 32) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                               dst->stream);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dst->d_vmax_sq, src->d_vmax_sq, sizeof(float), hipMemcpyDeviceToDevice, dst->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);
+    if (e != hipSuccess) return give_up(fail(TRAG_DEVICE_ERROR, std::string("clone: ") + hipGetErrorString(e)));
+    std::copy(src->h_dead.begin(), src->h_dead.begin() + std::min(src->h_dead.size(), dst->h_dead.size()),
+              dst->h_dead.begin());
+    dst->n_rows = n;
+    dst->n_live = src->n_live;
+    const bool mirror = src->d_mirror != nullptr;
+    if (mirror) {                        // (takes dst's own lock; nobody else knows dst yet)
+        ts = trag_store_set_bf16_mirror(dst, 1);
+        if (ts != TRAG_OK) return give_up(ts);
+    }
+    *out = dst;
+    return TRAG_OK;
+}
+
 trag_status trag_store_stream_probe(trag_store* s, uint32_t repeats, double* gb_per_s) {
     if (!s || !gb_per_s) return fail(TRAG_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);

@@ -9,6 +9,7 @@
 // Result<T, Error> becomes exceptions derived from trueno_rag::Error.
 // Header-only; link with -ltrag. There is no CPU fallback behind it.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <optional>
 #include <random>
@@ -103,6 +104,18 @@ class VectorStore {
 
     const VectorStoreConfig& config() const { return config_; }
 
+    // #[derive(Clone)], src/index.rs:322: an independent store with the same rows (copied inside
+    // HBM), ids and chunks. (Explicit, not a copy constructor: a copy is gigabytes.)
+    VectorStore clone() const {
+        trag_store* h = nullptr;
+        check(trag_store_clone(h_, &h));
+        VectorStore other(config_, h);
+        other.row_of_ = row_of_;
+        other.id_of_ = id_of_;
+        other.chunks_ = chunks_;
+        return other;
+    }
+
     // src/index.rs:359-375
     void insert(Chunk chunk) {
         if (!chunk.embedding) throw InvalidConfig("chunk must have embedding");
@@ -122,12 +135,42 @@ class VectorStore {
         chunks_.insert_or_assign(id, std::move(chunk));
     }
     // src/index.rs:378-383
+    // One call into the library for the new rows of the batch (ids already present are overwritten
+    // in place; an id that occurs twice in the batch keeps its last embedding). A chunk without an
+    // embedding or of the wrong dimension fails the call before anything is inserted.
     void insert_batch(std::vector<Chunk> chunks) {
-        for (auto& c : chunks) insert(std::move(c));
+        for (const auto& c : chunks) {
+            if (!c.embedding) throw InvalidConfig("chunk must have embedding");
+            if (c.embedding->size() != config_.dimension) throw DimensionMismatch(config_.dimension, c.embedding->size());
+        }
+        std::vector<Chunk> fresh;
+        std::unordered_map<ChunkId, size_t, ChunkIdHash> slot;
+        for (auto& c : chunks) {
+            if (row_of_.count(c.id)) { insert(std::move(c)); continue; }
+            auto it = slot.find(c.id);
+            if (it != slot.end()) { fresh[it->second] = std::move(c); continue; }
+            slot.emplace(c.id, fresh.size());
+            fresh.push_back(std::move(c));
+        }
+        if (fresh.empty()) return;
+        std::vector<float> flat;
+        flat.reserve(fresh.size() * config_.dimension);
+        for (const auto& c : fresh) flat.insert(flat.end(), c.embedding->begin(), c.embedding->end());
+        uint32_t first = 0;
+        check(trag_store_insert(h_, flat.data(), fresh.size(), (uint32_t)config_.dimension, &first), config_.dimension,
+              config_.dimension);
+        if (id_of_.size() < (size_t)first + fresh.size()) id_of_.resize((size_t)first + fresh.size());
+        for (size_t i = 0; i < fresh.size(); ++i) {
+            const ChunkId id = fresh[i].id;
+            row_of_[id] = first + (uint32_t)i;
+            id_of_[first + i] = id;
+            chunks_.insert_or_assign(id, std::move(fresh[i]));
+        }
     }
     // src/index.rs:386-412
     std::vector<std::pair<ChunkId, float>> search(const std::vector<float>& query_vector, size_t k) const {
         if (query_vector.size() != config_.dimension) throw DimensionMismatch(config_.dimension, query_vector.size());
+        k = std::min(k, len());  // the reference truncates: any k is legal
         std::vector<uint32_t> rows(k ? k : 1);
         std::vector<float> scores(k ? k : 1);
         uint32_t n = 0;
@@ -164,6 +207,7 @@ class VectorStore {
     trag_store* handle() const { return h_; }
 
   private:
+    VectorStore(VectorStoreConfig config, trag_store* adopted) : config_(config), h_(adopted) {}
     VectorStoreConfig config_;
     trag_store* h_ = nullptr;
     std::unordered_map<ChunkId, uint32_t, ChunkIdHash> row_of_;
@@ -214,7 +258,12 @@ class BM25Index {
         return out;
     }
 
+    // Re-adding a ChunkId REPLACES its document. (The reference keeps both postings, counts the chunk
+    // twice in doc_count and df while doc_lengths holds one entry, :176-204; that bookkeeping is not
+    // reproduced: a chunk is one document here, so a search never returns an id twice and fuse never
+    // counts it twice.)
     void add(const Chunk& chunk) {  // :176-204
+        remove(chunk.id);
         const std::vector<uint32_t> ids = term_ids(tokenize(chunk.content), true);
         const uint64_t off[2] = {0, ids.size()};
         const uint32_t dummy = 0;
@@ -229,6 +278,8 @@ class BM25Index {
     std::vector<std::pair<ChunkId, float>> search(const std::string& query, size_t k) const {  // :212-243
         const std::vector<std::string> toks = tokenize(query);
         std::vector<std::pair<ChunkId, float>> out;
+        // any k is legal in the reference (it truncates); the GPU select serves up to 4096 results
+        k = std::min<size_t>(std::min(k, len()), 4096);
         if (toks.empty() || k == 0) return out;
         const std::vector<uint32_t> ids = const_cast<BM25Index*>(this)->term_ids(toks, false);
         std::vector<uint32_t> docs(k);

@@ -116,6 +116,23 @@ class VectorStore:
     def close(self):
         self.__del__()
 
+    def clone(self) -> "VectorStore":
+        """`#[derive(Clone)]`, src/index.rs:322: an independent store with the same rows (copied
+        inside HBM), ids and chunks."""
+        other = object.__new__(type(self))
+        other._config = self._config
+        other._h = C.c_void_p()
+        _abi.check(_abi.lib().trag_store_clone(self._h, C.byref(other._h)))
+        other._row_of = dict(self._row_of)
+        other._id_of = dict(self._id_of)
+        other._chunks = dict(self._chunks)
+        return other
+
+    __copy__ = clone
+
+    def __repr__(self):   # `#[derive(Debug)]`
+        return f"VectorStore(config={self._config!r}, len={self.len()})"
+
     def config(self) -> VectorStoreConfig:
         return self._config
 
