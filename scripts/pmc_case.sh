@@ -12,11 +12,11 @@ acc=collections.defaultdict(list)
 for f in glob.glob(sys.argv[1]+"/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[(r["Kernel_Name"].split("(")[0][:70], r["Counter_Name"])].append(float(r["Counter_Value"]))
-out=open(sys.argv[2],"w"); out.write("kernel,counter,mean,launches\n")
+out=open(sys.argv[2],"w",newline=""); wr=csv.writer(out); wr.writerow(["kernel","counter","mean","launches"])
 tot=collections.defaultdict(float)
 for (k,c),v in acc.items(): tot[k]+=sum(v) if c in ("SQ_WAVE_CYCLES","SQ_BUSY_CYCLES","FETCH_SIZE","GRBM_GUI_ACTIVE") else 0
 top=sorted(tot,key=tot.get,reverse=True)[:4]
 for (k,c),v in sorted(acc.items()):
-    out.write("%s,%s,%.1f,%d\n"%(k,c,sum(v)/len(v),len(v)))
+    wr.writerow([k,c,"%.1f"%(sum(v)/len(v)),len(v)])
     if k in top: print("%-70s %-28s %16.1f  x%d"%(k,c,sum(v)/len(v),len(v)))
 PY

@@ -1709,7 +1709,22 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
             if (hipGetDevice(&dev) == hipSuccess)
                 (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
         }
-        const uint32_t grid = grid_for(n_tiles, 4, (uint32_t)n_cu);
+        uint32_t grid = grid_for(n_tiles, 4, (uint32_t)n_cu);
+        // Every wave walks its tiles in rounds (tile t belongs to wave t % n_waves), and the last
+        // round costs a whole round however few waves still have a tile in it: on a short scan
+        // (1 M rows = 15.26 rounds of 1024 waves) that is 5 % of the time for a quarter-full round.
+        // The pass is bound by memory, not by the number of workgroups in flight, so a few
+        // workgroups fewer that fill their last round do better: among 15/16 .. 16/16 of the CUs
+        // take the count that leaves the fewest empty tile slots.
+        if (grid == (uint32_t)n_cu && !getenv("TRAG_SCAN_FULL_GRID")) {
+            uint64_t best_slots = ~0ull;
+            uint32_t best = grid;
+            for (uint32_t g = (uint32_t)n_cu; g >= (uint32_t)n_cu - (uint32_t)n_cu / 16u && g > 0; --g) {
+                const uint64_t waves = 4ull * g, slots = (n_tiles + waves - 1) / waves * waves;
+                if (slots < best_slots) { best_slots = slots; best = g; }
+            }
+            grid = best;
+        }
         const uint32_t ep = (s.wbest && sparse_scan_pays(n_tiles, grid * 4u)) ? s.epoch : 0u;
         // load-by-load refill pays only for short rows (same run, MI355X: d = 128 +6 %, 384 -2 %,
         // 768 / 1536 / 4096 within noise)
