@@ -408,6 +408,10 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
             for (int ks = 0; ks < (MODE == 1 ? NCH : 0); ++ks) {
                 k_step(ks);
                 mp = test_some(accp, scp, ks * CH, CH, mp);
+                // (pins this piece of the test to this k-step: without it the compiler sinks all the
+                // pieces to the point where the running maximum is used and runs them in one burst
+                // between two MFMAs)
+                asm volatile("" :: "v"(mp));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (MODE == 1) list_hits(accp, scp, shp, mp, row0p, half);
