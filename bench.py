@@ -157,14 +157,24 @@ def main():
         m_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
         m_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
 
-    hybrid_out = []
     sparse_info = None
     if args.hybrid:
         assert world == 1 and B == 1, "--hybrid is a single-GPU, single-query step"
         cand = 50  # HybridRetrieverConfig::candidates_per_source, src/retrieve.rs:94
         fusion = pkg.FusionStrategy.RRF(60.0)
+        import importlib
+        rrf_device = importlib.import_module(pkg.__name__ + ".fusion").rrf_device
         h_rows = torch.zeros((n_q, cand), dtype=torch.int32, device="cuda")
         h_scores = torch.zeros((n_q, cand), dtype=torch.float32, device="cuda")
+        s_docs = torch.zeros((n_q, cand), dtype=torch.int32, device="cuda")
+        s_scores = torch.zeros((n_q, cand), dtype=torch.float32, device="cuda")
+        s_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+        s_st = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+        f_ids = torch.zeros((n_q, k), dtype=torch.int32, device="cuda")
+        f_scores = torch.zeros((n_q, k), dtype=torch.float32, device="cuda")
+        f_n = torch.zeros(n_q, dtype=torch.int32, device="cuda")
+        bm_stream = torch.cuda.Stream()
+        bm_done = torch.cuda.Event()
         # the sparse half: one synthetic document per corpus row (Zipf(1.0) over the vocabulary),
         # queries drawn from the same law
         bm25 = pkg.BM25Index(device=local)
@@ -173,22 +183,26 @@ def main():
         bm25.search_ids([0], 1)  # builds and uploads the inverted lists
         t_build = time.perf_counter() - t_build
         q_terms = sparse_queries(n_q, args.sparse_vocab, args.sparse_terms, seed + 101)
+        for j in range(min(4, n_q)):   # the host entry learns the select plan this corpus needs (crowded score
+            bm25.search_ids(q_terms[j], cand)   # bins at millions of documents); the device entry then uses it
         sparse_info = {"documents": n_local, "vocab": args.sparse_vocab, "tokens_per_doc": args.sparse_tokens,
                        "query_terms": args.sparse_terms, "postings": bm25.stats()["postings"],
                        "build_seconds": t_build}
 
     def hybrid_step(i):
-        """src/retrieve.rs:175-220: dense top-50 and BM25 top-50 (both on the GPU, on two
-        streams), then RRF(60) and the cut to k on the host."""
+        """src/retrieve.rs:175-220 without a host round trip: dense top-50 on the bench's stream, BM25
+        top-50 on a second stream beside it, then RRF(60) and the cut to k on the device
+        (trag_fuse_rrf_device), ordered behind both by an event. Nothing is synchronised per step."""
         store.search_device(Q.data_ptr() + i * d * esz, 1, cand, h_rows.data_ptr() + i * cand * esz,
                             h_scores.data_ptr() + i * cand * esz, out_n.data_ptr() + i * esz,
                             status.data_ptr() + i * esz, sptr)
-        s_docs, s_scores = bm25.search_ids(q_terms[i], cand)   # overlaps the dense scan
-        rows = h_rows[i].cpu().numpy()          # synchronises: the fusion runs on the host
-        scores = h_scores[i].cpu().numpy()
-        dense = list(zip(rows.tolist(), scores.tolist()))
-        sparse = list(zip(s_docs.tolist(), s_scores.tolist()))
-        hybrid_out.append(fusion.fuse(dense, sparse)[:k])
+        bm25.search_ids_device(q_terms[i], cand, s_docs.data_ptr() + i * cand * esz, s_scores.data_ptr() + i * cand * esz,
+                               s_n.data_ptr() + i * esz, s_st.data_ptr() + i * esz, bm_stream.cuda_stream)
+        bm_done.record(bm_stream)
+        stream.wait_event(bm_done)
+        rrf_device(h_rows.data_ptr() + i * cand * esz, out_n.data_ptr() + i * esz, cand,
+                   s_docs.data_ptr() + i * cand * esz, s_n.data_ptr() + i * esz, cand, 1, 60.0, k,
+                   f_ids.data_ptr() + i * k * esz, f_scores.data_ptr() + i * k * esz, f_n.data_ptr() + i * esz, sptr)
 
     Q_host = Q.cpu().numpy() if args.host else None
     host_out = {}
@@ -278,6 +292,23 @@ def main():
         final_rows, final_scores = host_out["rows"][-1].astype(np.uint32), host_out["scores"][-1]
         uncertified = 0   # the host entry repeats unfinished queries itself
     parity = {"uncertified_queries": uncertified, "sorted": bool(np.all(final_scores[:-1] >= final_scores[1:]))}
+    if args.hybrid:
+        # the sparse half finished on the device for every timed query, and the device fusion of the last
+        # query equals the host fusion (trag_fuse) of the same two lists; its sparse list equals the host entry's
+        parity["sparse_unfinished_queries"] = int((s_st[args.warmup:] != 0).sum().item())
+        i = n_q - 1
+        dn, sn = int(out_n[i].item()), int(s_n[i].item())
+        dense = list(zip(h_rows[i, :dn].cpu().numpy().tolist(), h_scores[i, :dn].cpu().numpy().tolist()))
+        sparse = list(zip(s_docs[i, :sn].cpu().numpy().tolist(), s_scores[i, :sn].cpu().numpy().tolist()))
+        want = fusion.fuse(dense, sparse)[:args.k]   # (k is the candidate count from here on)
+        fn = int(f_n[i].item())
+        got_ids, got_scores = f_ids[i, :fn].cpu().numpy().tolist(), f_scores[i, :fn].cpu().numpy()
+        parity["device_fusion_equals_host_fusion"] = bool(
+            got_ids == [int(x) for x, _ in want]
+            and got_scores.tobytes() == np.asarray([sc for _, sc in want], dtype=np.float32).tobytes())
+        hd, hs = bm25.search_ids(q_terms[i], cand)
+        parity["sparse_device_equals_host_entry"] = bool(
+            hd.tolist() == [x for x, _ in sparse] and hs.tobytes() == s_scores[i, :sn].cpu().numpy().tobytes())
     if world > 1 or sharded:
         # the device merge of the last query against a host merge of every rank's own list
         # (descending score, ascending global row; gathered as plain Python objects)
@@ -342,7 +373,7 @@ def main():
             "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if one_gpu else ""),
             "config": {"workload": (f"{n_total}x{d} fp32 corpus in HBM, hybrid step: dense cosine top-50 + BM25 "
                                     f"top-50 over {n_total} synthetic documents (both on the GPU) -> RRF(60) on "
-                                    f"the host -> top-{args.k}") if args.hybrid else
+                                    f"the device -> top-{args.k}; no host round trip in the step") if args.hybrid else
                        f"{n_total}x{d} fp32 corpus in HBM, {B} quer{'y' if B == 1 else 'ies'} per step, {args.metric} top-{k}",
                        "rows": n_total, "dim": d, "k": k, "batch": B, "metric": args.metric,
                        "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",

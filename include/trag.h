@@ -194,6 +194,20 @@ trag_status trag_fuse_rrf(const uint64_t *dense_ids, uint32_t nd, const uint64_t
                           uint32_t ns, float k, uint64_t *out_ids, float *out_scores,
                           uint32_t *out_n);
 
+/* RRF (src/fusion.rs:68-84) for a batch of queries whose dense and sparse result lists are in
+ * device memory (trag_store_search_device, trag_bm25_search_device): the hybrid step of
+ * src/retrieve.rs:175-220 without a host round trip, n_queries fusions in one launch. Ids are u32 in
+ * one id space (row index = document index: every chunk went into both indices in the same
+ * order). Query b's dense list is d_dense_ids[b * dense_stride .. + d_dense_n[b]) (d_dense_n NULL:
+ * dense_stride entries), its sparse list likewise; at most 1024 entries per list. Writes, per
+ * query, the best min(k_out, distinct ids) entries at b * k_out and their count. Same arithmetic
+ * and order as trag_fuse. Enqueued on hip_stream, no synchronisation. */
+trag_status trag_fuse_rrf_device(const uint32_t *d_dense_ids, const uint32_t *d_dense_n,
+                                 uint32_t dense_stride, const uint32_t *d_sparse_ids,
+                                 const uint32_t *d_sparse_n, uint32_t sparse_stride,
+                                 uint32_t n_queries, float k, uint32_t k_out, uint32_t *d_out_ids,
+                                 float *d_out_scores, uint32_t *d_out_n, void *hip_stream);
+
 /* Merge per-shard top-k lists (row-sharded corpus, one list per shard, global
  * row ids) into the global top-k with the same ordering rule as search.
  * lists are n_lists x k_in, list_n[i] valid entries each. Host code. */

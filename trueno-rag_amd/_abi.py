@@ -114,6 +114,9 @@ SIGNATURES = {
     "trag_fuse": (C.c_int, [C.c_uint32, C.c_float, _u64p, _fp, C.c_uint32, _u64p, _fp, C.c_uint32,
                             _u64p, _fp, _u32p]),
     "trag_fuse_rrf": (C.c_int, [_u64p, C.c_uint32, _u64p, C.c_uint32, C.c_float, _u64p, _fp, _u32p]),
+    "trag_fuse_rrf_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_uint32, C.c_float, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     "trag_merge_topk": (C.c_int, [_u32p, _fp, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
     "trag_store_last_stats": (C.c_int, [_H, C.POINTER(SearchStats)]),
     "trag_bm25_create": (C.c_int, [C.POINTER(BM25Config), C.POINTER(_H)]),

@@ -90,3 +90,15 @@ class FusionStrategy:
                                         si.ctypes.data_as(u64p), ss.ctypes.data_as(fp), si.size,
                                         out_ids.ctypes.data_as(u64p), out_scores.ctypes.data_as(fp), C.byref(n)))
         return [(back[int(out_ids[i])], float(out_scores[i])) for i in range(n.value)]
+
+
+def rrf_device(dense_ids_ptr: int, dense_n_ptr: int, dense_stride: int, sparse_ids_ptr: int, sparse_n_ptr: int,
+               sparse_stride: int, n_queries: int, k: float, k_out: int, out_ids_ptr: int, out_scores_ptr: int,
+               out_n_ptr: int, stream: int = 0) -> None:
+    """RRF (src/fusion.rs:68-84) for a batch of queries whose dense and sparse lists are in device
+    memory, as u32 ids of one id space; every argument named *_ptr is a device address. Enqueued on
+    `stream`, no synchronisation (trag_fuse_rrf_device)."""
+    _abi.check(_abi.lib().trag_fuse_rrf_device(dense_ids_ptr, dense_n_ptr or None, dense_stride, sparse_ids_ptr,
+                                               sparse_n_ptr or None, sparse_stride, n_queries, k, k_out, out_ids_ptr,
+                                               out_scores_ptr, out_n_ptr, stream or None))
+

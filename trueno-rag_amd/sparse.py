@@ -161,6 +161,16 @@ class BM25Index:
                                                C.byref(n)))
         return docs[:n.value].copy(), scores[:n.value].copy()
 
+    def search_ids_device(self, query_terms, k: int, d_docs_ptr: int, d_scores_ptr: int, d_n_ptr: int,
+                          d_status_ptr: int, stream: int = 0) -> None:
+        """search_ids with device-resident outputs (k entries, one count, one status word), enqueued
+        on `stream` without synchronising; status 3 asks the caller to repeat the query through
+        search_ids (trag_bm25_search_device). The query terms are host memory."""
+        q = np.ascontiguousarray(query_terms, dtype=np.uint32)
+        _abi.check(_abi.lib().trag_bm25_search_device(self._h, _u32ptr(q if q.size else np.zeros(1, np.uint32)),
+                                                      q.size, k, d_docs_ptr, d_scores_ptr, d_n_ptr, d_status_ptr,
+                                                      stream or None))
+
     def search(self, query: str, k: int) -> List[Tuple[ChunkId, float]]:
         terms = self.tokenize(query)
         if not terms:
