@@ -107,7 +107,8 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                  const float* __restrict__ norm2, const uint32_t* __restrict__ dead, uint32_t n_rows,
                  uint32_t d, uint32_t n_queries, uint32_t q_tiles, uint32_t tile_step,
                  SearchCtl* __restrict__ ctls, const float* __restrict__ thr,
-                 uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_t* __restrict__ cand) {
+                 uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_t* __restrict__ cand,
+                 uint32_t* __restrict__ cvals) {
     constexpr int NT = 64 * WGM * WGN;  // threads
     constexpr int PF = 1;               // steps of operand loads in flight (2 and 3 measured slower, also with the
                                         // mirror's small 32-register step: 256 queries x 1M x 768 0.634 -> 0.660 ms)
@@ -407,8 +408,16 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                 const uint32_t q = q0 + (uint32_t)(wm * 32 * TM + m * 32) + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)half;
                 const bool ok = n ? live[1] : live[0];
                 if (ok && q < n_queries) {
+                    // the hit's approximate value goes with it (qs_prune_kernel shortens the list with
+                    // it before anything is scored exactly); the accumulator is picked by a run-time
+                    // index: rare, so the register-indexed move it compiles to costs nothing measurable
+                    const float a = n ? acc[m][1][r] : acc[m][0][r];
+                    const float v = __builtin_fmaf(a, n ? scale[1] : scale[0], n ? nshift[1] : nshift[0]);
                     const uint32_t pos = atomicAdd(&ctls[q].cand_count, 1u);
-                    if (pos < CAND_CAP) cand[(size_t)q * CAND_CAP + pos] = n ? rows_[1] : rows_[0];
+                    if (pos < CAND_CAP) {
+                        cand[(size_t)q * CAND_CAP + pos] = n ? rows_[1] : rows_[0];
+                        cvals[(size_t)q * CAND_CAP + pos] = __float_as_uint(v);
+                    }
                 }
             }
         }
@@ -461,7 +470,7 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
 #define TRAG_LAUNCH_BF16(TM, WGM, WGN)                                                                       \
     hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, TM, WGM, WGN, MODE, MIR>), dim3(grid), dim3(64 * WGM * WGN), 0, \
                        st, a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, \
-                       a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand)
+                       a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys)
     if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
     else if (variant == 1) TRAG_LAUNCH_BF16(2, 1, 4);  // 64 x 256
     else if (variant == 2) TRAG_LAUNCH_BF16(2, 2, 2);  // 128 x 128
@@ -469,7 +478,7 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
         if constexpr (MIR)
             hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, 4, 2, 4, MODE, true, true>), dim3(grid), dim3(512), 0, st,
                                a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows,
-                               a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand);
+                               a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys);
     } else TRAG_LAUNCH_BF16(4, 2, 4);                  // 256 x 256, eight waves (two per SIMD)
 #undef TRAG_LAUNCH_BF16
 }
@@ -492,6 +501,9 @@ static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArg
     hipLaunchKernelGGL(shift_threshold_kernel<METRIC>, dim3((n_queries + 255) / 256), dim3(256), 0, st, s.ctls,
                        n_queries, a.dim, s.thr);
     launch_gemm_bf16<METRIC, 1, MIR>(n_queries, a, d_mirror, d_norm2, s, 1, st);
+    // the lists hold every row above the sample's threshold, with its approximate value: keep the
+    // rows within 2 eps of the list's need-th largest value (trag_qstat.hip)
+    launch_qs_prune(METRIC, s, n_queries, a.dim, st);
 }
 
 void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padded, uint32_t dim, uint16_t* qb,

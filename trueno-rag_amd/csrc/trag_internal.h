@@ -93,7 +93,8 @@ struct Bf16Scratch {
     uint32_t* tmax;      // [queries][tmax_stride]: tile maxima of the sample pass
     size_t tmax_stride;
     uint32_t* cand;      // [queries][CAND_CAP]
-    uint32_t* ckeys;     // [queries][CAND_CAP]: exact ordered keys of the candidates
+    uint32_t* ckeys;     // [queries][CAND_CAP]: first the candidates' approximate values (prefilter -> prune), then
+                         // their exact ordered keys (exact finish)
 };
 
 constexpr uint32_t ST_OVERFLOW = 2;     // more candidates than the final sort holds: repeat exactly
@@ -184,6 +185,9 @@ double bf16_list_estimate(uint64_t n_rows, uint32_t need, uint32_t dim);
 // most queries one launch_bf16_scan / launch_bf16_finish pair takes at this dimension
 uint32_t bf16_max_batch(uint32_t dim, uint32_t metric, uint32_t n_queries);
 bool bf16_uses_qs(uint32_t dim, uint32_t metric, uint32_t n_queries);
+// Shortens every query's candidate list to the rows within 2 eps of its need-th largest approximate value
+// (cand / ckeys hold rows and values side by side); updates thr[] and the control blocks.
+void launch_qs_prune(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t dim, hipStream_t st);
 // query-stationary form of the prefilter (trag_qstat.hip)
 bool qs_supports(uint32_t dim, uint32_t metric);
 uint32_t qs_group_queries(uint32_t dim);

@@ -611,6 +611,15 @@ void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padde
 void launch_shift_threshold(uint32_t metric, SearchCtl* ctls, uint32_t n_queries, uint32_t dim, float* thr,
                             hipStream_t st);
 
+void launch_qs_prune(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t dim, hipStream_t st) {
+    if (metric == TRAG_COSINE)
+        hipLaunchKernelGGL(qs_prune_kernel<0>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim);
+    else if (metric == TRAG_EUCLIDEAN)
+        hipLaunchKernelGGL(qs_prune_kernel<1>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim);
+    else
+        hipLaunchKernelGGL(qs_prune_kernel<2>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim);
+}
+
 // The whole prefilter for up to qs_max_batch(dim) queries: sample pass, thresholds, full pass, prune.
 // The caller has run launch_batch_prep (norms, control blocks).
 hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
@@ -628,12 +637,7 @@ hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& 
     launch_shift_threshold(a.metric, s.ctls, n_queries, a.dim, s.thr, st);
     if (d_mirror) qs_launch<1, true>(n_queries, a, d_mirror, d_norm2, s, 1, st);
     else qs_launch<1, false>(n_queries, a, d_mirror, d_norm2, s, 1, st);
-    if (a.metric == TRAG_COSINE)
-        hipLaunchKernelGGL(qs_prune_kernel<0>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, a.dim);
-    else if (a.metric == TRAG_EUCLIDEAN)
-        hipLaunchKernelGGL(qs_prune_kernel<1>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, a.dim);
-    else
-        hipLaunchKernelGGL(qs_prune_kernel<2>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, a.dim);
+    launch_qs_prune(a.metric, s, n_queries, a.dim, st);
     return hipGetLastError();
 }
 
