@@ -336,7 +336,7 @@ trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
     const uint32_t qcap = std::min<uint32_t>(std::max<uint32_t>(nq, 1), bf16_max_batch(s->cfg.dim, s->cfg.metric, nq));
     const uint64_t tiles = (uint64_t)s->cap_rows / 32 + 32;  // one maximum per 32 rows, sample step 1 at worst
     if (s->bf16.qb && s->bf16_tiles_cap >= tiles && s->bf16_q_cap >= qcap) return TRAG_OK;
-    void* old[] = {s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys};
+    void* old[] = {s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys, s->bf16.rowc};
     for (void* p : old)
         if (p) (void)hipFree(p);
     s->bf16 = Bf16Scratch{};
@@ -351,6 +351,7 @@ trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
     HIP_TRY(hipMalloc(&s->bf16.tmax, (size_t)qcap * s->bf16.tmax_stride * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->bf16.cand, (size_t)qcap * CAND_CAP * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->bf16.ckeys, (size_t)qcap * CAND_CAP * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&s->bf16.rowc, ((size_t)s->cap_rows + 64) * 2 * sizeof(float)));
     s->bf16_tiles_cap = tiles;
     s->bf16_q_cap = qcap;
     return TRAG_OK;
@@ -850,7 +851,7 @@ void trag_store_destroy(trag_store* s) {
     if (s->order_ev) (void)hipEventDestroy(s->order_ev);
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->d_mirror,
                     s->batch.qpad, s->batch.ctls, s->batch.keys, s->batch.tmax, s->batch.cand,
-                    s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys,
+                    s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys, s->bf16.rowc,
                     s->zero_block, s->scratch.cand, s->scratch.ckeys, s->scratch.keys, s->scratch.tmax, s->scratch.wmax, s->scratch.wbest,
                     s->m_zero_block, s->mscratch.keys, s->mscratch.tmax, s->mscratch.wmax,
                     s->d_sort, s->d_q, s->d_out_block};

@@ -93,6 +93,7 @@ struct Bf16Scratch {
     uint32_t* tmax;      // [queries][tmax_stride]: tile maxima of the sample pass
     size_t tmax_stride;
     uint32_t* cand;      // [queries][CAND_CAP]
+    float* rowc;         // [rows rounded up to 64][2]: per row (scale, shift) of the query-stationary form's score test
     uint32_t* ckeys;     // [queries][CAND_CAP]: first the candidates' approximate values (prefilter -> prune), then
                          // their exact ordered keys (exact finish)
 };

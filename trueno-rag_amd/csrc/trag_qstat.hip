@@ -75,9 +75,9 @@ __device__ __forceinline__ float max_over_32_lanes(float x) {
 template <int KS, int NW, int QB, int RT, int MODE, bool MIR, int DP, bool NTL>
 __global__ void __launch_bounds__(64 * NW, NW / 4)
 qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mirror,
-               const __bf16* __restrict__ Qb, const float* __restrict__ norm2,
-               const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t n_queries, uint32_t G,
-               uint32_t S, uint32_t tile_step, uint32_t metric,
+               const __bf16* __restrict__ Qb, const float* __restrict__ rowc_g,
+               uint32_t n_rows, uint32_t n_queries, uint32_t G,
+               uint32_t S, uint32_t tile_step,
                SearchCtl* __restrict__ ctls, const float* __restrict__ thr, uint32_t* __restrict__ tmax,
                size_t tmax_stride, uint32_t* __restrict__ cand, uint32_t* __restrict__ cvals) {
     constexpr int D = KS * 16;
@@ -91,15 +91,15 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     constexpr int NL = 32 * PPR / NT;          // pieces per thread and subtile
     constexpr int NF = 4;                      // fragment reads in flight
     constexpr int PER = KS / NL;               // MFMAs between two staged pieces
-    constexpr int HITS = 512, FLUSH_AT = 256;  // LDS hit list: capacity, and the fill that triggers a flush
+    constexpr int HITS = 64;                   // LDS hit list of one wave and tile parity: capacity
     // DP: subtiles whose loads are in flight (a load is issued DP steps before its piece is written)
     constexpr int LOOK = 1 + (NSUB - 1 + DP) / NSUB;   // the furthest tile ahead a step loads from
     static_assert(32 * PPR % NT == 0 && RT % 32 == 0 && D % 128 == 0 && KS >= NF && KS % NL == 0, "tile geometry");
     static_assert(NSUB % DP == 0 || DP == 2 * NSUB, "ring geometry");
     __shared__ __attribute__((aligned(16))) uint32_t img[NSLOT][32 * STRIDE];
     __shared__ __attribute__((aligned(8))) float rowc[NSLOT][32][2];   // per row: scale, shift (see below)
-    __shared__ uint32_t hit_q[2][MODE == 1 ? HITS : 1], hit_row[2][MODE == 1 ? HITS : 1], hit_v[2][MODE == 1 ? HITS : 1];
-    __shared__ uint32_t hit_n[2];
+    __shared__ uint32_t hit_q[2][NW][MODE == 1 ? HITS : 1], hit_row[2][NW][MODE == 1 ? HITS : 1], hit_v[2][NW][MODE == 1 ? HITS : 1];
+    __shared__ uint32_t hit_n[2][NW];   // entries in each list (written back by its wave at the end of every tile)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -165,6 +165,9 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         for (int rr = 0; rr < NA; ++rr) {
             const uint32_t q = q0 + 32u * (uint32_t)(rr >> 4) + qrow(rr & 15);
             th[rr] = q < n_queries ? thr[q] : INFINITY;
+#ifdef QS_EXP_NOHIT
+            th[rr] = INFINITY;
+#endif
             // A query outside the bound's range (threshold -inf) would list every row: its list is
             // marked as overflowed once, here, and it takes no further part (the final stage reports
             // the overflow and the host repeats the query with the exact scan).
@@ -173,7 +176,7 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                 th[rr] = INFINITY;
             }
         }
-        if (tid < 2) hit_n[tid] = 0u;
+        if (tid < 2 * NW) hit_n[tid / NW][tid % NW] = 0u;
         drain_vmem();
     }
 
@@ -186,95 +189,83 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         loff[i] = (uint32_t)(row * STRIDE + c * (MIR ? 4 : 2));
     }
     u32x4 pre[DP][NL];
-    // every thread also carries the norm and the tombstone word of row (tid & 31) of the staged
-    // subtile (32 threads would do; all of them doing the same keeps the step free of branches,
-    // which is what lets the compiler count the loads in flight instead of draining them)
-    float pre_nb2[DP];
-    uint32_t pre_dead[DP];
+    // every thread also carries the (scale, shift) pair of row (tid & 31) of the staged subtile (32
+    // threads would do; all of them doing the same keeps the step free of branches, which is what
+    // lets the compiler count the loads in flight instead of draining them)
+    float2 pre_rc[DP];
 #pragma unroll
-    for (int k = 0; k < DP; ++k) { pre_nb2[k] = 0.0f; pre_dead[k] = 0u; }
+    for (int k = 0; k < DP; ++k) pre_rc[k] = make_float2(0.0f, -INFINITY);
     // load piece i of the subtile that starts at row0 into slot k of the staging registers. The
-    // subtile is one contiguous block of 32 PPR pieces; a piece past the corpus' end (a partial last
-    // tile, or a tile of a unit past the stream's last) reads the corpus' last piece instead: its row
-    // counts as removed, whatever it holds. No branch: the same instructions run for every tile,
-    // which keeps the loop a single body whose loads the compiler can count.
-    const uint64_t last_piece = (uint64_t)n_rows * (uint64_t)PPR - 1u;
-    const u32x4* const src = MIR ? reinterpret_cast<const u32x4*>(mirror) : reinterpret_cast<const u32x4*>(corpus);
+    // subtile is one contiguous block of memory: its address is a wave-uniform base (scalar registers)
+    // plus a per-thread byte offset fixed for the kernel's life, so a piece costs no address
+    // arithmetic in the vector ALU. Nothing is clamped: the store's row buffers (f32 rows, mirror)
+    // hold a multiple of 64 rows and rowc_g is written up to that multiple, so the rows of a partial
+    // last tile are readable memory; what they hold does not matter, their scale / shift say
+    // "takes no part". (A unit past the stream's last is read from tile 0 and never used.) No branch:
+    // the same instructions run for every tile, which keeps the loop a single body.
+    const char* const src = MIR ? reinterpret_cast<const char*>(mirror) : reinterpret_cast<const char*>(corpus);
+    constexpr size_t ROW_BYTES = (size_t)D * (MIR ? 2 : 4);
+    const uint32_t voff = (uint32_t)tid * 16u;
+    const uint32_t rc_off = (uint32_t)(tid & 31) * 8u;
     auto issue_piece = [&](int k, int i, uint32_t row0) __attribute__((always_inline)) {
-        uint64_t gp = (uint64_t)row0 * (uint64_t)PPR + (uint64_t)(uint32_t)(i * NT + tid);
-        gp = gp < last_piece ? gp : last_piece;
-        pre[k][i] = NTL ? __builtin_nontemporal_load(src + gp) : src[gp];
-        if (i == 0) {
-            uint32_t row = row0 + (uint32_t)(tid & 31);
-            row = row < n_rows - 1u ? row : n_rows - 1u;
-            uint32_t word = row >> 5;
-            asm volatile("" : "+v"(word));   // (a vector load: as a scalar load it would share the LDS counter
-                                              // and drain the fragment ring once per step)
-            pre_dead[k] = dead[word];
-            pre_nb2[k] = norm2[row];
-        }
+        const char* base = src + (size_t)row0 * ROW_BYTES + (size_t)(i * NT) * 16u;   // (uniform)
+        const u32x4* p = reinterpret_cast<const u32x4*>(base + voff);
+        pre[k][i] = NTL ? __builtin_nontemporal_load(p) : *p;
+        if (i == 0)
+            pre_rc[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rowc_g) + (size_t)row0 * 8u + rc_off);
     };
-    // v = the row-dependent part of the score = fma(dot, scale, shift): cosine dot / ||v||, dot
-    // product dot, Euclidean 2 dot - ||v||^2. Rows that take no part (removed, past the end):
-    // scale 0, shift -inf. Rows whose norm is outside the bound's range must always be
-    // candidates: scale 0, shift +inf (the sample pass leaves them out). The reciprocal square
-    // root is the hardware's (1 ulp): v only has to be within the bound's 1 % slack of its value.
-    auto write_piece = [&](int k, int i, int sl, uint32_t row0) __attribute__((always_inline)) {
+    // (scale, shift): see qs_rowc_kernel
+    auto write_piece = [&](int k, int i, int sl, uint32_t) __attribute__((always_inline)) {
         if (MIR) {
             *reinterpret_cast<u32x4*>(&img[sl][loff[i]]) = pre[k][i];
         } else {
             const bf16x4 hv = __builtin_convertvector(__builtin_bit_cast(v4f, pre[k][i]), bf16x4);
             *reinterpret_cast<u32x2*>(&img[sl][loff[i]]) = __builtin_bit_cast(u32x2, hv);
         }
-        if (i == 0) {
-            const uint32_t row = row0 + (uint32_t)(tid & 31);
-            const float nb2 = metric == 2u ? 1.0f : pre_nb2[k];
-            const bool live = row < n_rows && !((pre_dead[k] >> (row & 31u)) & 1u);
-            const bool forced = !(nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY));
-            float sc = metric == 0u ? (nb2 > 0.0f ? __builtin_amdgcn_rsqf(nb2) : 0.0f) : (metric == 1u ? 2.0f : 1.0f);
-            float sh = metric == 1u ? -nb2 : 0.0f;
-            sc = forced ? 0.0f : sc;
-            sh = forced ? INFINITY : sh;
-            sc = live ? sc : 0.0f;
-            sh = live ? sh : -INFINITY;
-            float2 v2 = make_float2(sc, sh);
-            *reinterpret_cast<float2*>(&rowc[sl][tid & 31][0]) = v2;   // (16 threads store the same pair: harmless)
-        }
+        if (i == 0) *reinterpret_cast<float2*>(&rowc[sl][tid & 31][0]) = pre_rc[k];   // (16 threads store the same pair: harmless)
     };
 
     bf16x8 fr[NF];     // the fragment ring
     auto frag = [&](int sl, int ks) __attribute__((always_inline)) {
         return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&img[sl][r * STRIDE + 4 * h + ks * 8]));
     };
-    // one hit: query q, corpus row, approximate value v -> this tile parity's LDS list. A list that
-    // is full (a burst: hundreds of hits inside one tile) marks the query's list in memory as
-    // overflowed instead: the host repeats that query exactly.
-    auto append = [&](int par, uint32_t q, uint32_t row, float v) __attribute__((always_inline)) {
-        const uint32_t pos = atomicAdd(&hit_n[par], 1u);
-        if (pos < (uint32_t)HITS) {
-            hit_q[par][pos] = q;
-            hit_row[par][pos] = row;
-            hit_v[par][pos] = __float_as_uint(v);
-        } else {
-            atomicMax(&ctls[q].cand_count, CAND_CAP + 1u);
-            drain_vmem();
-        }
-    };
-    // wave 0 only, while no wave appends to list `par`
-    auto flush = [&](int par) __attribute__((always_inline)) {
-        const uint32_t n = min(hit_n[par], (uint32_t)HITS);
-        for (uint32_t i = (uint32_t)lane; i < n; i += 64u) {
-            const uint32_t q = hit_q[par][i];
+    // Hits go to lists in LDS first, one per wave and tile parity, so that listing needs no atomic
+    // and no wait: `hits_here` is the wave's own count for the current tile's parity (wave-uniform,
+    // read from hit_n at the start of a tile and written back at its end). Wave 0 empties the lists of
+    // the OTHER parity into the queries' lists in memory, at the start of a tile, when one of them is
+    // a quarter full: nobody appends to them during that tile, and only wave 0's loads are drained by the
+    // atomics' returns. A wave whose own list is full (a burst of hits: a row that scores high for most
+    // queries at once) empties it into memory itself before it goes on.
+    uint32_t hits_here = 0u;
+    auto flush_own = [&](int par) __attribute__((always_inline)) {
+        if ((uint32_t)lane < hits_here) {
+            const uint32_t q = hit_q[par][wid][lane];
             const uint32_t gp = atomicAdd(&ctls[q].cand_count, 1u);
             if (gp < CAND_CAP) {
-                cand[(size_t)q * CAND_CAP + gp] = hit_row[par][i];
-                cvals[(size_t)q * CAND_CAP + gp] = hit_v[par][i];
+                cand[(size_t)q * CAND_CAP + gp] = hit_row[par][wid][lane];
+                cvals[(size_t)q * CAND_CAP + gp] = hit_v[par][wid][lane];
+            }
+        }
+        drain_vmem();
+        hits_here = 0u;
+    };
+    auto flush = [&](int par) __attribute__((always_inline)) {
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t n = min(hit_n[par][w], (uint32_t)HITS);
+            if ((uint32_t)lane < n) {
+                const uint32_t q = hit_q[par][w][lane];
+                const uint32_t gp = atomicAdd(&ctls[q].cand_count, 1u);
+                if (gp < CAND_CAP) {
+                    cand[(size_t)q * CAND_CAP + gp] = hit_row[par][w][lane];
+                    cvals[(size_t)q * CAND_CAP + gp] = hit_v[par][w][lane];
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) hit_n[par] = 0u;
+        if (lane < NW) hit_n[par][lane] = 0u;
         drain_vmem();
     };
+    static_assert(HITS == 64, "one lane per list entry in flush(); a wave's hits of one round always fit an empty list");
     // MODE 0: the largest value of each (query, subtile), as an ordered key
     auto epilogue = [&](const v16f (&acc)[QB], int sl, uint32_t idx) __attribute__((always_inline)) {
         const float2 rc = *reinterpret_cast<const float2*>(&rowc[sl][r][0]);
@@ -310,24 +301,48 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
             m = fmaxf(m, __builtin_fmaf(acc[e >> 4][e & 15], sc, -th[e]));   // (fmaxf drops a NaN operand)
         return m;
     };
-    // ... and the rare continuation: list the hits of a lane whose test did not fail (a NaN counts
-    // as a hit; a row that takes no part, scale 0 and shift -inf, has none).
+    // ... and the continuation (a few tenths of the steps at 10 wanted rows per query and a million
+    // corpus rows): list the hits. A NaN counts as a hit; a row that takes no part (scale 0 and
+    // shift -inf) has none. The branch is taken by the whole wave or not at all, the hit bits of a
+    // lane are formed without branches, and the lanes that have one write it at consecutive
+    // positions of the wave's own list: counting by ballot, no atomic, nothing to wait for.
+    uint32_t qmask = 0u;   // bit e: accumulator e belongs to a query of the batch
+#pragma unroll
+    for (int e = 0; e < NA; ++e) {
+        const uint32_t q = q0 + 32u * (uint32_t)(e >> 4) + qrow(e & 15);
+        qmask |= q < n_queries ? (1u << e) : 0u;
+    }
+    static_assert(NA <= 32, "hit bits of a lane fit one word");
     auto list_hits = [&](const v16f (&acc)[QB], float sc, float sh, float m, uint32_t row0, int par) __attribute__((always_inline)) {
         const bool maybe = !(m + sh < 0.0f);
-        if (maybe) {
-            const uint32_t row = row0 + (uint32_t)r;
+        if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
             const bool live = sh != -INFINITY || sc != 0.0f;
-            // (opaque move: without it the list addresses of the sixteen queries are hoisted
-            // out of the step loop and held in registers the fragment reads need)
-            uint32_t qb = q0 + 4u * (uint32_t)h;
-            asm volatile("" : "+v"(qb));
+            uint32_t w = 0u;
 #pragma unroll
-            for (int e = 0; e < NA; ++e) {
-                const int rr = e & 15;
-                const float a = acc[e >> 4][rr];
-                const float v = __builtin_fmaf(a, sc, sh);
-                const uint32_t q = qb + (uint32_t)(32 * (e >> 4) + (rr & 3) + 8 * (rr >> 2));
-                if (!(__builtin_fmaf(a, sc, -th[e]) + sh < 0.0f) && live && q < n_queries) append(par, q, row, v);
+            for (int e = 0; e < NA; ++e)
+                w |= !(__builtin_fmaf(acc[e >> 4][e & 15], sc, -th[e]) + sh < 0.0f) ? (1u << e) : 0u;
+            w = live ? (w & qmask) : 0u;
+            const uint32_t row = row0 + (uint32_t)r;
+            uint32_t qb = q0 + 4u * (uint32_t)h;
+            unsigned long long any = __builtin_amdgcn_ballot_w64(w != 0u);
+            while (any != 0ull) {
+                const bool act = w != 0u;
+                const uint32_t bit = act ? (uint32_t)__builtin_ctz(w) : 0u;
+                w &= w - 1u;
+                float v = 0.0f;   // the value of accumulator `bit` (a chain of selects: the index differs by lane)
+#pragma unroll
+                for (int e = 0; e < NA; ++e) v = bit == (uint32_t)e ? __builtin_fmaf(acc[e >> 4][e & 15], sc, sh) : v;
+                const uint32_t add = (uint32_t)__builtin_popcountll(any);   // <= 64 = the list's capacity
+                if (hits_here + add > (uint32_t)HITS) flush_own(par);
+                const uint32_t pos = hits_here + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
+                if (act) {
+                    const uint32_t rr = bit & 15u;
+                    hit_q[par][wid][pos] = qb + 32u * (bit >> 4) + (rr & 3u) + 8u * (rr >> 2);
+                    hit_row[par][wid][pos] = row;
+                    hit_v[par][wid][pos] = __float_as_uint(v);
+                }
+                hits_here += add;
+                any = __builtin_amdgcn_ballot_w64(w != 0u);
             }
         }
     };
@@ -371,10 +386,20 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     uint32_t row0p = 0u;
     constexpr int NCH = KS < 16 ? KS : 16;       // k-steps of a step that are followed by a piece of the test
     constexpr int CH = (NA + NCH - 1) / NCH;     // accumulators per piece
+#ifdef QS_STAMP
+    unsigned long long st_work = 0, st_bar = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_all0 = st_t0;
+#endif
     auto run_tile = [&](auto odd_tag, uint32_t n) __attribute__((always_inline)) {
         constexpr int ODD = decltype(odd_tag)::value ? 1 : 0;
         const int half = (int)(n & 1u);   // which half of the images this tile's subtiles are in; its hit list
-        if (MODE == 1 && wid == 0 && hit_n[half ^ 1] >= (uint32_t)FLUSH_AT) flush(half ^ 1);
+        if (MODE == 1) {
+            hits_here = hit_n[half][wid];
+            if (wid == 0) {
+                uint32_t fullest = lane < NW ? hit_n[half ^ 1][lane] : 0u;
+                fullest = wave_max_u32(fullest);
+                if (fullest >= (uint32_t)HITS / 4u) flush(half ^ 1);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NF; ++j) fr[j] = frag(half * NSUB, j);
 #pragma unroll
@@ -386,6 +411,14 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
             const uint32_t row0 = unit[0] * rows_per_unit + 32u * (uint32_t)sub;
             const uint32_t row0_write = unit[1] * rows_per_unit + 32u * (uint32_t)sub;
             const uint32_t row0_issue = unit[it] * rows_per_unit + 32u * (uint32_t)isub;
+#ifdef QS_PRIO
+            // the two waves of a SIMD take turns at being preferred by the issue arbiter (which, left
+            // alone, always prefers the older one: waves 0..3)
+            if (NW == 8) {
+                if ((wid >= 4) == ((sub & 1) != 0)) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
             v16f acc[QB];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
@@ -436,7 +469,20 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                 row0p = row0;
             }
         }
+        if (MODE == 1 && lane == 0) hit_n[half][wid] = min(hits_here, (uint32_t)HITS);
+#ifdef QS_STAMP
+        {
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            st_work += t1 - st_t0;
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            st_bar += t2 - t1;
+            st_t0 = t2;
+        }
+#elif defined(QS_EXP_NOBAR)
+#else
         __syncthreads();
+#endif
     };
     constexpr bool BY_PARITY = DP > NSUB;
     for (uint32_t n = 0; n < n_mine; ++n) {
@@ -447,15 +493,45 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         const uint32_t u = next_unit();
         unit[LOOK] = u == NO_UNIT ? 0u : u;
     }
+#ifdef QS_STAMP
+    if (MODE == 1 && lane == 0 && (blockIdx.x % 67u) == 5u)
+        printf("blk %u wave %d tiles %u work %llu bar %llu total %llu\n", blockIdx.x, wid, n_mine, st_work, st_bar,
+               (unsigned long long)__builtin_amdgcn_s_memtime() - st_all0);
+#endif
     if (MODE == 1) {
         // the last step's accumulators; then, when every wave has listed its hits, both lists
+        hits_here = hit_n[0][wid];
         mp = test_some(accp, scp, 0, NA, mp);
         list_hits(accp, scp, shp, mp, row0p, 0);
+        if (lane == 0) hit_n[0][wid] = min(hits_here, (uint32_t)HITS);
         __syncthreads();
         if (wid == 0) {
             flush(0);
             flush(1);
         }
+    }
+}
+
+// Per corpus row, once per batch: the row-dependent part of a score is v = fma(dot, scale, shift) --
+// cosine dot / ||v||, dot product dot, Euclidean 2 dot - ||v||^2. Rows that take no part (removed,
+// past the end): scale 0, shift -inf. Rows whose norm is outside the bound's range must always be
+// candidates: scale 0, shift +inf (the sample pass leaves them out). The reciprocal square root is
+// the hardware's (1 ulp): v only has to be within the bound's 1 % slack of its value. Written for
+// every row up to the next multiple of 64 (the GEMM's tiles read that far).
+__global__ void __launch_bounds__(256)
+qs_rowc_kernel(const float* __restrict__ norm2, const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t n_pad,
+               uint32_t metric, float2* __restrict__ rowc) {
+    for (uint32_t row = blockIdx.x * 256u + threadIdx.x; row < n_pad; row += gridDim.x * 256u) {
+        const bool live = row < n_rows && !row_is_dead(dead, row);
+        const float nb2 = (metric == 2u || !live) ? 1.0f : norm2[row];
+        const bool forced = !(nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY));
+        float sc = metric == 0u ? (nb2 > 0.0f ? __builtin_amdgcn_rsqf(nb2) : 0.0f) : (metric == 1u ? 2.0f : 1.0f);
+        float sh = metric == 1u ? -nb2 : 0.0f;
+        sc = forced ? 0.0f : sc;
+        sh = forced ? INFINITY : sh;
+        sc = live ? sc : 0.0f;
+        sh = live ? sh : -INFINITY;
+        rowc[row] = make_float2(sc, sh);
     }
 }
 
@@ -564,8 +640,8 @@ static void qs_launch_tile(uint32_t n_queries, const ScanArgs& a, const uint16_t
     const uint32_t S = std::max<uint32_t>(1u, (uint32_t)cu_per_xcd / G);
     const uint32_t grid = 8u * S * G;
     hipLaunchKernelGGL((qs_gemm_kernel<KS, NW, QB, RT, MODE, MIR, DP, NTL>), dim3(grid), dim3(64 * NW), 0, st, a.corpus,
-                       d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, n_queries, G, S,
-                       tile_step, a.metric, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys);
+                       d_mirror, reinterpret_cast<const __bf16*>(s.qb), s.rowc, a.n_rows, n_queries, G, S,
+                       tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys);
 }
 
 // The corpus is read by G workgroups of one XCD: keep it in L2 for them; a single reader (one
@@ -627,6 +703,11 @@ hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& 
     const uint32_t QW = qs_group_queries(a.dim);
     const uint32_t padded = (n_queries + QW - 1) / QW * QW;
     launch_queries_to_bf16(d_Q, n_queries, padded, a.dim, s.qb, st);
+    {
+        const uint32_t n_pad = (a.n_rows + 63u) / 64u * 64u;
+        hipLaunchKernelGGL(qs_rowc_kernel, dim3(std::min<uint32_t>((n_pad + 255u) / 256u, 2048u)), dim3(256), 0, st,
+                           d_norm2, a.dead, a.n_rows, n_pad, a.metric, reinterpret_cast<float2*>(s.rowc));
+    }
     const uint32_t step = qs_sample_step(a.n_rows, need, a.dim);
     const uint32_t RT = qs_tile_rows(a.dim);
     if (d_mirror) qs_launch<0, true>(n_queries, a, d_mirror, d_norm2, s, step, st);
