@@ -250,15 +250,23 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         hits_here = 0u;
     };
     auto flush = [&](int par) __attribute__((always_inline)) {
+        // (all the atomics first, then the stores that need their results: one round trip to memory
+        // for the whole flush instead of one per list -- wave 0 is stalled for that long, and at the
+        // tile's barrier so is everybody else)
+        uint32_t fq[NW], fpos[NW];
+#pragma unroll
         for (int w = 0; w < NW; ++w) {
             const uint32_t n = min(hit_n[par][w], (uint32_t)HITS);
-            if ((uint32_t)lane < n) {
-                const uint32_t q = hit_q[par][w][lane];
-                const uint32_t gp = atomicAdd(&ctls[q].cand_count, 1u);
-                if (gp < CAND_CAP) {
-                    cand[(size_t)q * CAND_CAP + gp] = hit_row[par][w][lane];
-                    cvals[(size_t)q * CAND_CAP + gp] = hit_v[par][w][lane];
-                }
+            fq[w] = (uint32_t)lane < n ? hit_q[par][w][lane] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            fpos[w] = fq[w] != 0xFFFFFFFFu ? atomicAdd(&ctls[fq[w]].cand_count, 1u) : CAND_CAP;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (fpos[w] < CAND_CAP) {
+                cand[(size_t)fq[w] * CAND_CAP + fpos[w]] = hit_row[par][w][lane];
+                cvals[(size_t)fq[w] * CAND_CAP + fpos[w]] = hit_v[par][w][lane];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -295,11 +303,13 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     // the accumulators of step u are tested, a few at a time, BETWEEN the MFMAs of step u + 1, where
     // the vector ALU is idle anyway; done after the step they would stall the matrix pipe of both
     // waves of the SIMD, which reach their step ends together.
-    auto test_some = [&](const v16f (&acc)[QB], float sc, int first, int count, float m) __attribute__((always_inline)) {
+    // The running maximum is kept per group of four accumulators (NG maxima): the same number of
+    // operations, and the continuation below then looks only at the groups that can hold a hit.
+    constexpr int NG = NA / 4;
+    auto test_some = [&](const v16f (&acc)[QB], float sc, int first, int count, float (&m)[NG]) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = first; e < first + count && e < NA; ++e)
-            m = fmaxf(m, __builtin_fmaf(acc[e >> 4][e & 15], sc, -th[e]));   // (fmaxf drops a NaN operand)
-        return m;
+            m[e >> 2] = fmaxf(m[e >> 2], __builtin_fmaf(acc[e >> 4][e & 15], sc, -th[e]));   // (fmaxf drops a NaN operand)
     };
     // ... and the continuation (a few tenths of the steps at 10 wanted rows per query and a million
     // corpus rows): list the hits. A NaN counts as a hit; a row that takes no part (scale 0 and
@@ -313,25 +323,38 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         qmask |= q < n_queries ? (1u << e) : 0u;
     }
     static_assert(NA <= 32, "hit bits of a lane fit one word");
-    auto list_hits = [&](const v16f (&acc)[QB], float sc, float sh, float m, uint32_t row0, int par) __attribute__((always_inline)) {
-        const bool maybe = !(m + sh < 0.0f);
-        if (__builtin_amdgcn_ballot_w64(maybe) != 0ull) {
+    auto list_hits = [&](const v16f (&acc)[QB], float sc, float sh, const float (&m)[NG], uint32_t row0, int par) __attribute__((always_inline)) {
+        float mall = m[0];
+#pragma unroll
+        for (int g = 1; g < NG; ++g) mall = fmaxf(mall, m[g]);
+        if (__builtin_amdgcn_ballot_w64(!(mall + sh < 0.0f)) != 0ull) {
             const bool live = sh != -INFINITY || sc != 0.0f;
             uint32_t w = 0u;
 #pragma unroll
-            for (int e = 0; e < NA; ++e)
-                w |= !(__builtin_fmaf(acc[e >> 4][e & 15], sc, -th[e]) + sh < 0.0f) ? (1u << e) : 0u;
+            for (int g = 0; g < NG; ++g) {
+                if (__builtin_amdgcn_ballot_w64(!(m[g] + sh < 0.0f)) != 0ull) {   // (typically one group of the wave)
+#pragma unroll
+                    for (int e = 4 * g; e < 4 * g + 4; ++e)
+                        w |= !(__builtin_fmaf(acc[e >> 4][e & 15], sc, -th[e]) + sh < 0.0f) ? (1u << e) : 0u;
+                }
+            }
             w = live ? (w & qmask) : 0u;
             const uint32_t row = row0 + (uint32_t)r;
             uint32_t qb = q0 + 4u * (uint32_t)h;
             unsigned long long any = __builtin_amdgcn_ballot_w64(w != 0u);
             while (any != 0ull) {
                 const bool act = w != 0u;
-                const uint32_t bit = act ? (uint32_t)__builtin_ctz(w) : 0u;
+                const uint32_t bit = act ? (uint32_t)__builtin_ctz(w) : 0xFFFFFFFFu;
                 w &= w - 1u;
-                float v = 0.0f;   // the value of accumulator `bit` (a chain of selects: the index differs by lane)
+                float a = 0.0f;   // accumulator `bit` (selects: the index differs by lane; only the groups in play)
 #pragma unroll
-                for (int e = 0; e < NA; ++e) v = bit == (uint32_t)e ? __builtin_fmaf(acc[e >> 4][e & 15], sc, sh) : v;
+                for (int g = 0; g < NG; ++g) {
+                    if (__builtin_amdgcn_ballot_w64((bit >> 2) == (uint32_t)g) != 0ull) {
+#pragma unroll
+                        for (int e = 4 * g; e < 4 * g + 4; ++e) a = bit == (uint32_t)e ? acc[e >> 4][e & 15] : a;
+                    }
+                }
+                const float v = __builtin_fmaf(a, sc, sh);
                 const uint32_t add = (uint32_t)__builtin_popcountll(any);   // <= 64 = the list's capacity
                 if (hits_here + add > (uint32_t)HITS) flush_own(par);
                 const uint32_t pos = hits_here + __builtin_amdgcn_mbcnt_hi((uint32_t)(any >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)any, 0u));
@@ -382,7 +405,9 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) accp[qb][e] = 0.0f;
-    float scp = 0.0f, shp = -INFINITY, mp = -INFINITY;
+    float scp = 0.0f, shp = -INFINITY, mp[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) mp[g] = -INFINITY;
     uint32_t row0p = 0u;
     constexpr int NCH = KS < 16 ? KS : 16;       // k-steps of a step that are followed by a piece of the test
     constexpr int CH = (NA + NCH - 1) / NCH;     // accumulators per piece
@@ -395,9 +420,8 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         if (MODE == 1) {
             hits_here = hit_n[half][wid];
             if (wid == 0) {
-                uint32_t fullest = lane < NW ? hit_n[half ^ 1][lane] : 0u;
-                fullest = wave_max_u32(fullest);
-                if (fullest >= (uint32_t)HITS / 4u) flush(half ^ 1);
+                const uint32_t fill = lane < NW ? hit_n[half ^ 1][lane] : 0u;
+                if (__builtin_amdgcn_ballot_w64(fill >= (uint32_t)HITS / 4u) != 0ull) flush(half ^ 1);
             }
         }
 #pragma unroll
@@ -440,11 +464,11 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
 #pragma unroll
             for (int ks = 0; ks < (MODE == 1 ? NCH : 0); ++ks) {
                 k_step(ks);
-                mp = test_some(accp, scp, ks * CH, CH, mp);
+                test_some(accp, scp, ks * CH, CH, mp);
                 // (pins this piece of the test to this k-step: without it the compiler sinks all the
                 // pieces to the point where the running maximum is used and runs them in one burst
                 // between two MFMAs)
-                asm volatile("" :: "v"(mp));
+                asm volatile("" :: "v"(mp[(ks * CH) >> 2]));
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (MODE == 1) list_hits(accp, scp, shp, mp, row0p, half);
@@ -465,7 +489,8 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                 for (int qb = 0; qb < QB; ++qb) accp[qb] = acc[qb];
                 scp = rc.x;
                 shp = rc.y;
-                mp = -INFINITY;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) mp[g] = -INFINITY;
                 row0p = row0;
             }
         }
@@ -501,7 +526,7 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     if (MODE == 1) {
         // the last step's accumulators; then, when every wave has listed its hits, both lists
         hits_here = hit_n[0][wid];
-        mp = test_some(accp, scp, 0, NA, mp);
+        test_some(accp, scp, 0, NA, mp);
         list_hits(accp, scp, shp, mp, row0p, 0);
         if (lane == 0) hit_n[0][wid] = min(hits_here, (uint32_t)HITS);
         __syncthreads();
