@@ -346,7 +346,11 @@ trag_status ensure_bf16_scratch(trag_store* s, uint32_t nq) {
     // the sample pass covers at most every tile (step 1) but normally 1/8 of them
     s->bf16.tmax_stride = (size_t)tiles;
     HIP_TRY(hipMalloc(&s->bf16.qb, padded * s->cfg.dim * sizeof(uint16_t)));
-    HIP_TRY(hipMalloc(&s->bf16.thr, (size_t)qcap * sizeof(float)));
+    // thresholds, then the ladder state of the tightening thresholds: level, (level 0, step), counters
+    HIP_TRY(hipMalloc(&s->bf16.thr, padded * (4 + DYN_LEVELS) * sizeof(float)));
+    s->bf16.dyn_lvl = reinterpret_cast<uint32_t*>(s->bf16.thr + padded);
+    s->bf16.dyn_lad = s->bf16.thr + 2 * padded;
+    s->bf16.dyn_cnt = reinterpret_cast<uint32_t*>(s->bf16.thr + 4 * padded);
     HIP_TRY(hipMalloc(&s->bf16.ctls, (size_t)qcap * sizeof(SearchCtl)));
     HIP_TRY(hipMalloc(&s->bf16.tmax, (size_t)qcap * s->bf16.tmax_stride * sizeof(uint32_t)));
     HIP_TRY(hipMalloc(&s->bf16.cand, (size_t)qcap * CAND_CAP * sizeof(uint32_t)));

@@ -60,24 +60,37 @@ queries_to_bf16_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t
 // with the exact scan.
 template <int METRIC>
 __global__ void shift_threshold_kernel(SearchCtl* __restrict__ ctls, uint32_t n_queries, uint32_t d,
-                                       float* __restrict__ thr) {
+                                       float* __restrict__ thr, uint32_t padded, uint32_t* __restrict__ dyn_lvl,
+                                       float* __restrict__ dyn_lad, uint32_t* __restrict__ dyn_cnt) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_queries) return;
-    SearchCtl* ctl = ctls + q;
-    const uint32_t tk = ctl->t_key;
-    const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
-    float t = -INFINITY, v = -INFINITY;
-    const bool in_range = na * vmax < 1e30f && (METRIC != 0 || na > 0.0f);  // false for NaN too
-    if (tk >= 0x007FFFFFu && in_range) {
-        const float eps = bf16_eps<METRIC>(d, na, vmax);
-        const float tv = key_score(tk);
-        if (METRIC == 0) { t = tv / na - 2.02f * eps; v = t * na; }
-        else if (METRIC == 1) { t = (tv - ctl->na_sq) - 2.02f * eps; v = t + ctl->na_sq; }
-        else { t = tv - 2.02f * eps; v = t; }
+    if (q >= padded) return;
+    // the ladder of the thresholds that tighten during the full pass (trag_device.h): level 0 is
+    // the threshold found here, a step is a quarter of 2.02 eps in v-space; no ladder (step 0)
+    // for a query without a finite threshold, +inf for the padding behind the batch
+    float t = -INFINITY, v = q < n_queries ? -INFINITY : INFINITY, step = 0.0f;
+    if (q < n_queries) {
+        SearchCtl* ctl = ctls + q;
+        const uint32_t tk = ctl->t_key;
+        const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
+        const bool in_range = na * vmax < 1e30f && (METRIC != 0 || na > 0.0f);  // false for NaN too
+        if (tk >= 0x007FFFFFu && in_range) {
+            const float eps = bf16_eps<METRIC>(d, na, vmax);
+            const float tv = key_score(tk);
+            if (METRIC == 0) { t = tv / na - 2.02f * eps; v = t * na; step = 2.02f * eps * na; }
+            else if (METRIC == 1) { t = (tv - ctl->na_sq) - 2.02f * eps; v = t + ctl->na_sq; step = 2.02f * eps; }
+            else { t = tv - 2.02f * eps; v = t; step = 2.02f * eps; }
+            step *= 1.0f / (float)DYN_SUB;
+        }
+        if (!(t == t) || !(v == v)) { t = -INFINITY; v = -INFINITY; }
+        if (!(v > -INFINITY && v < INFINITY && step > 0.0f && step < INFINITY)) step = 0.0f;
+        ctl->t_key = t > -INFINITY ? score_key(t) : 1u;
+        thr[q] = v;
+#pragma unroll
+        for (uint32_t j = 0; j < DYN_LEVELS; ++j) dyn_cnt[(size_t)q * DYN_LEVELS + j] = 0u;
     }
-    if (!(t == t) || !(v == v)) { t = -INFINITY; v = -INFINITY; }
-    ctl->t_key = t > -INFINITY ? score_key(t) : 1u;
-    thr[q] = v;
+    dyn_lvl[q] = 0u;
+    dyn_lad[2 * q] = v;
+    dyn_lad[2 * q + 1] = step;
 }
 
 // ---------------------------------------------------------------------------
@@ -108,7 +121,8 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                  uint32_t d, uint32_t n_queries, uint32_t q_tiles, uint32_t tile_step,
                  SearchCtl* __restrict__ ctls, const float* __restrict__ thr,
                  uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_t* __restrict__ cand,
-                 uint32_t* __restrict__ cvals) {
+                 uint32_t* __restrict__ cvals, uint32_t need, uint32_t* __restrict__ dyn_lvl,
+                 const float* __restrict__ dyn_lad, uint32_t* __restrict__ dyn_cnt) {
     constexpr int NT = 64 * WGM * WGN;  // threads
     constexpr int PF = 1;               // steps of operand loads in flight (2 and 3 measured slower, also with the
                                         // mirror's small 32-register step: 256 queries x 1M x 768 0.634 -> 0.660 ms)
@@ -127,6 +141,10 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     uint32_t* const As = lds0;
     uint32_t* const Bs = lds0 + BM * (DMA ? 32 : BF_LD);
     __shared__ __attribute__((aligned(16))) float qs_s[BM];  // MODE 1: the queries' thresholds
+    // ... which tighten during the pass: a workgroup starts from the ladder level the pass has reached
+    // by then (trag_device.h: dyn_level_value), and its hits are counted for the levels above it
+    __shared__ float qs_lad[MODE == 1 ? BM : 1][2];
+    __shared__ uint32_t qs_lvl[MODE == 1 ? BM : 1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid % WGN;
 
@@ -140,7 +158,16 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     if (nt >= n_row_tiles) return;
     const uint32_t q0 = qt * BM, n0 = nt * BN;
 
-    if (MODE == 1 && tid < BM) qs_s[tid] = (q0 + tid < n_queries) ? thr[q0 + tid] : INFINITY;
+    if (MODE == 1 && tid < BM) {
+        // (the ladder arrays are padded to a multiple of 256 queries: +inf thresholds behind the batch)
+        const uint32_t q = q0 + (uint32_t)tid;
+        const uint32_t lv = dyn_lvl[q];
+        const float t0 = dyn_lad[2 * q], step = dyn_lad[2 * q + 1];
+        qs_lvl[tid] = lv;
+        qs_lad[tid][0] = t0;
+        qs_lad[tid][1] = step;
+        qs_s[tid] = dyn_level_value(lv, t0, step);
+    }
 
     const uint32_t nk = d / BF_K;
     v16f acc[TM][2];
@@ -413,11 +440,23 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                     // index: rare, so the register-indexed move it compiles to costs nothing measurable
                     const float a = n ? acc[m][1][r] : acc[m][0][r];
                     const float v = __builtin_fmaf(a, n ? scale[1] : scale[0], n ? nshift[1] : nshift[0]);
+                    // the ladder levels this row vouches for, above the one the workgroup started from:
+                    // their counters and the list cursor in one round trip to memory
+                    const uint32_t ql = q - q0;
+                    const int jh = dyn_hit_level(v, qs_lad[ql][0], qs_lad[ql][1], (int)DYN_LEVELS, (int)DYN_SUB);
+                    const int jlo = max((int)qs_lvl[ql], jh - (int)DYN_MAXINC);
+                    uint32_t old[DYN_MAXINC];
+#pragma unroll
+                    for (int i = 0; i < (int)DYN_MAXINC; ++i)
+                        old[i] = jh - i > jlo ? atomicAdd(&dyn_cnt[(size_t)q * DYN_LEVELS + (uint32_t)(jh - i)], 1u) : 0xFFFFFFF0u;
                     const uint32_t pos = atomicAdd(&ctls[q].cand_count, 1u);
                     if (pos < CAND_CAP) {
                         cand[(size_t)q * CAND_CAP + pos] = n ? rows_[1] : rows_[0];
                         cvals[(size_t)q * CAND_CAP + pos] = __float_as_uint(v);
                     }
+#pragma unroll
+                    for (int i = 0; i < (int)DYN_MAXINC; ++i)
+                        if (old[i] + 1u == need) atomicMax(&dyn_lvl[q], (uint32_t)(jh - i));
                 }
             }
         }
@@ -430,22 +469,36 @@ bool bf16_supports(uint32_t dim, uint32_t metric) {
 
 // Corpus tiles per sampled tile. The sample must hold many more 32-row groups than
 // the rows wanted, or its k-th maximum says little; and it must be dense enough
-// that the candidate lists stay short: a list holds about need * step * w rows,
-// w = the growth of the rank over a score interval of 2 eps near the top of the
-// corpus (for unit-norm rows with independent components the scores have
+// that the candidate lists stay short. With a fixed threshold a list would hold about
+// need * step * w rows, w = the growth of the rank over a score interval of 2 eps near the
+// top of the corpus (for unit-norm rows with independent components the scores have
 // sigma = 1 / sqrt(d) and the top sits near 5 sigma: w = exp(10 eps sqrt(d)),
-// 4.8 at d = 384, 9.5 at 768, ~390 at 4096). Clustered corpora grow faster; their
-// lists overflow and those queries are repeated exactly.
+// 4.8 at d = 384, 9.5 at 768, ~390 at 4096). The thresholds tighten during the full pass
+// (trag_device.h: dyn_hit_level): after n rows a query's threshold follows the need-th best of
+// those n, so the list grows like need * w * (1 + ln step) and a sparse sample costs little.
+// Clustered corpora grow faster; their lists overflow and those queries are repeated exactly.
+double bf16_rank_growth(uint32_t dim) {
+    const double fd = (double)dim;
+    const double eps = 0.0078125 * 1.003 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
+    return std::exp(10.0 * eps * std::sqrt(fd));
+}
+
+// most tiles between two sampled ones for which a list is expected to stay within 1024 rows
+double bf16_step_by_list(uint32_t need, uint32_t dim) {
+    const double nw = (double)(need ? need : 1) * bf16_rank_growth(dim);
+    const double fixed = 1024.0 / nw;                              // thresholds that never move
+    const double x = 1024.0 / (1.5 * nw) - 1.0;                    // 1.5: the levels lag behind the rows seen
+    const double tight = x > 0.0 ? std::exp(std::min(x, 20.0)) : 1.0;
+    return std::max(fixed, tight);
+}
+
 uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
     const uint64_t n_tile64 = (n_rows + 63) / 64;
     if (need == 0) need = 1;
     uint64_t step = n_tile64 / (64ull * need);
-    const double fd = (double)dim;
-    const double eps = 0.0078125 * 1.003 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
-    const double w = std::exp(10.0 * eps * std::sqrt(fd));
-    const double by_list = 1024.0 / ((double)need * w);
+    const double by_list = bf16_step_by_list(need, dim);
     if ((double)step > by_list) step = (uint64_t)by_list;
-    return (uint32_t)(step < 1 ? 1 : (step > 8 ? 8 : step));
+    return (uint32_t)(step < 1 ? 1 : (step > 16 ? 16 : step));
 }
 
 // workgroup tile by batch size: queries x corpus rows
@@ -459,7 +512,7 @@ static uint32_t bf16_tile_rows(uint32_t n_queries) {
 
 template <int METRIC, int MODE, bool MIR>
 static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
-                             const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
+                             const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st) {
     const int variant = bf16_variant(n_queries);
     const uint32_t BM = variant == 0 ? 32 : (variant == 1 ? 64 : (variant == 2 ? 128 : 256));
     const uint32_t BN = bf16_tile_rows(n_queries);
@@ -470,7 +523,8 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
 #define TRAG_LAUNCH_BF16(TM, WGM, WGN)                                                                       \
     hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, TM, WGM, WGN, MODE, MIR>), dim3(grid), dim3(64 * WGM * WGN), 0, \
                        st, a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, \
-                       a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys)
+                       a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys, \
+                       need, s.dyn_lvl, s.dyn_lad, s.dyn_cnt)
     if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
     else if (variant == 1) TRAG_LAUNCH_BF16(2, 1, 4);  // 64 x 256
     else if (variant == 2) TRAG_LAUNCH_BF16(2, 2, 2);  // 128 x 128
@@ -478,7 +532,8 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
         if constexpr (MIR)
             hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, 4, 2, 4, MODE, true, true>), dim3(grid), dim3(512), 0, st,
                                a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows,
-                               a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys);
+                               a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys,
+                               need, s.dyn_lvl, s.dyn_lad, s.dyn_cnt);
     } else TRAG_LAUNCH_BF16(4, 2, 4);                  // 256 x 256, eight waves (two per SIMD)
 #undef TRAG_LAUNCH_BF16
 }
@@ -491,16 +546,16 @@ static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArg
     hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min<uint32_t>(1024, (padded * a.dim / 4 + 255) / 256)),
                        dim3(256), 0, st, d_Q, n_queries, padded, a.dim, reinterpret_cast<__bf16*>(s.qb));
     const uint32_t step = bf16_sample_step(a.n_rows, need, a.dim);
-    launch_gemm_bf16<METRIC, 0, MIR>(n_queries, a, d_mirror, d_norm2, s, step, st);
+    launch_gemm_bf16<METRIC, 0, MIR>(n_queries, a, d_mirror, d_norm2, s, step, need, st);
     // 64-row tiles the sample pass wrote maxima for (its last 128/256-row tile may be partial)
     const uint32_t BN = bf16_tile_rows(n_queries);
     const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
     const uint32_t pass_tiles = (n_row_tiles + step - 1) / step;
     const uint32_t n_tile64 = pass_tiles * (BN / 32);  // maxima per 32 rows; every sampled workgroup writes all of its own
     launch_tau_select(s.tmax, s.tmax_stride, n_tile64, s.ctls, n_queries, st);
-    hipLaunchKernelGGL(shift_threshold_kernel<METRIC>, dim3((n_queries + 255) / 256), dim3(256), 0, st, s.ctls,
-                       n_queries, a.dim, s.thr);
-    launch_gemm_bf16<METRIC, 1, MIR>(n_queries, a, d_mirror, d_norm2, s, 1, st);
+    hipLaunchKernelGGL(shift_threshold_kernel<METRIC>, dim3(padded / 256), dim3(256), 0, st, s.ctls,
+                       n_queries, a.dim, s.thr, padded, s.dyn_lvl, s.dyn_lad, s.dyn_cnt);
+    launch_gemm_bf16<METRIC, 1, MIR>(n_queries, a, d_mirror, d_norm2, s, 1, need, st);
     // the lists hold every row above the sample's threshold, with its approximate value: keep the
     // rows within 2 eps of the list's need-th largest value (trag_qstat.hip)
     launch_qs_prune(METRIC, s, n_queries, a.dim, st);
@@ -512,12 +567,15 @@ void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padde
                        dim3(256), 0, st, d_Q, n_queries, padded, dim, reinterpret_cast<__bf16*>(qb));
 }
 
-void launch_shift_threshold(uint32_t metric, SearchCtl* ctls, uint32_t n_queries, uint32_t dim, float* thr,
+void launch_shift_threshold(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t padded, uint32_t dim,
                             hipStream_t st) {
-    const dim3 grid((n_queries + 255) / 256), block(256);
-    if (metric == TRAG_COSINE) hipLaunchKernelGGL(shift_threshold_kernel<0>, grid, block, 0, st, ctls, n_queries, dim, thr);
-    else if (metric == TRAG_EUCLIDEAN) hipLaunchKernelGGL(shift_threshold_kernel<1>, grid, block, 0, st, ctls, n_queries, dim, thr);
-    else hipLaunchKernelGGL(shift_threshold_kernel<2>, grid, block, 0, st, ctls, n_queries, dim, thr);
+    const dim3 grid((padded + 255) / 256), block(256);
+#define TRAG_SHIFT(M) hipLaunchKernelGGL(shift_threshold_kernel<M>, grid, block, 0, st, s.ctls, n_queries, dim, s.thr, \
+                                         padded, s.dyn_lvl, s.dyn_lad, s.dyn_cnt)
+    if (metric == TRAG_COSINE) TRAG_SHIFT(0);
+    else if (metric == TRAG_EUCLIDEAN) TRAG_SHIFT(1);
+    else TRAG_SHIFT(2);
+#undef TRAG_SHIFT
 }
 
 // Which of the two forms serves a batch. The query-stationary form (trag_qstat.hip) reads the
@@ -560,13 +618,16 @@ hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs
     return hipGetLastError();
 }
 
-// Rows a query's candidate list is expected to hold on a corpus of independent
-// components (see bf16_sample_step); AUTO avoids the prefilter when it nears the list size.
+// Rows a query's candidate list would hold, with a threshold that never moved and a sample of at
+// most every 8th tile, on a corpus of independent components; AUTO avoids the prefilter when
+// it nears the list size.
 double bf16_list_estimate(uint64_t n_rows, uint32_t need, uint32_t dim) {
-    const double fd = (double)dim;
-    const double eps = 0.0078125 * 1.003 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
-    return (double)(need ? need : 1) * (double)bf16_sample_step(n_rows, need, dim) *
-           std::exp(10.0 * eps * std::sqrt(fd));
+    if (need == 0) need = 1;
+    const double w = bf16_rank_growth(dim);
+    double step = (double)(((n_rows + 63) / 64) / (64ull * need));
+    step = std::min(step, 1024.0 / ((double)need * w));
+    step = step < 1.0 ? 1.0 : (step > 8.0 ? 8.0 : std::floor(step));
+    return (double)need * step * w;
 }
 
 }  // namespace trag

@@ -82,6 +82,36 @@ __device__ __forceinline__ float bf16_eps(uint32_t d, float na, float vmax) {
     return 2.0f * c * na * vmax + (2.0f * (float)d + 64.0f) * 5.9604645e-08f * span * span * 1.01f + 1e-30f;
 }
 
+// bf16 prefilter, thresholds that tighten during the full pass. A query's candidate threshold
+// (in the space of v, the row-dependent part of the score) starts at the value T0 its sample
+// gave and may rise along the ladder  T(m) = fma(m, step, T0),  step = 2.02 eps / SUB:  once
+// `need` different rows have been seen with v >= T(j + SUB) = T(j) + 2.02 eps, the need-th best
+// approximate value A of the whole corpus is at least T(j) + 2.02 eps, every row of the exact
+// top `need` has v >= A - 2 eps > T(j), and T(j) is as good a threshold as T0 was. Every party
+// evaluates the ladder with this one expression, so a level means the same value everywhere.
+__device__ __forceinline__ float dyn_level_value(uint32_t level, float t0, float step) {
+    return __builtin_fmaf((float)level, step, t0);
+}
+
+// The highest level a row with approximate value v vouches for: the largest j with
+// T(j + sub) <= v, at most levels - 1; negative: none (also for a v that is not finite -- rows
+// outside the bound's range are candidates whatever the threshold and prove nothing -- and for a
+// query without a ladder, step 0).
+__device__ __forceinline__ int dyn_hit_level(float v, float t0, float step, int levels, int sub) {
+    if (!(step > 0.0f) || !(v < INFINITY) || !(t0 > -INFINITY) || !(t0 < INFINITY)) return -1;
+    float x = (v - t0) / step;
+    if (!(x >= 0.0f)) return -1;
+    x = fminf(x, (float)(levels + sub));
+    int m = (int)x;
+    // the ladder's own arithmetic has the last word (the quotient above may be one step off)
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+        if (m >= 0 && !(dyn_level_value((uint32_t)m, t0, step) <= v)) --m;
+    if (m < 0 || !(dyn_level_value((uint32_t)m, t0, step) <= v)) return -1;
+    const int j = m - sub;
+    return j < levels - 1 ? j : levels - 1;
+}
+
 // Same integer hash as the host generator used by the tests.
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;

@@ -85,10 +85,20 @@ struct BatchScratch {
     uint32_t* cand;      // [queries][CAND_CAP]
 };
 
+// bf16 prefilter, thresholds that tighten during the full pass (trag_device.h: dyn_hit_level).
+// Every query has a ladder of DYN_LEVELS thresholds, DYN_SUB steps per 2.02 eps, above the one its
+// sample gave; a hit is counted for at most DYN_MAXINC levels.
+constexpr uint32_t DYN_LEVELS = 32;
+constexpr uint32_t DYN_SUB = 4;
+constexpr uint32_t DYN_MAXINC = 4;
+
 // Device scratch of a block of queries on the bf16-prefilter path (no score matrix).
 struct Bf16Scratch {
     uint16_t* qb;        // queries as bf16, zero-padded to a multiple of 256 rows
-    float* thr;          // per query: the full pass's candidate threshold
+    float* thr;          // per query: the full pass's candidate threshold (the sample's; after the prune stage: the final one)
+    uint32_t* dyn_lvl;   // per query (padded to 256): the ladder level the full pass has reached (only grows)
+    float* dyn_lad;      // per query (padded): the ladder, two floats: level 0 and the step
+    uint32_t* dyn_cnt;   // [queries][DYN_LEVELS]: rows seen that vouch for each level
     SearchCtl* ctls;     // one per query
     uint32_t* tmax;      // [queries][tmax_stride]: tile maxima of the sample pass
     size_t tmax_stride;

@@ -30,6 +30,11 @@
 #include "trag_device.h"
 #include "trag_internal.h"
 
+// Entries the lists of one tile parity must hold together before wave 0 moves them to memory.
+#ifndef QS_FLUSH_MIN
+#define QS_FLUSH_MIN 16
+#endif
+
 namespace trag {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -78,8 +83,10 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                const __bf16* __restrict__ Qb, const float* __restrict__ rowc_g,
                uint32_t n_rows, uint32_t n_queries, uint32_t G,
                uint32_t S, uint32_t tile_step,
-               SearchCtl* __restrict__ ctls, const float* __restrict__ thr, uint32_t* __restrict__ tmax,
-               size_t tmax_stride, uint32_t* __restrict__ cand, uint32_t* __restrict__ cvals) {
+               SearchCtl* __restrict__ ctls, uint32_t* __restrict__ tmax,
+               size_t tmax_stride, uint32_t* __restrict__ cand, uint32_t* __restrict__ cvals,
+               uint32_t need, uint32_t* __restrict__ dyn_lvl, const float* __restrict__ dyn_lad,
+               uint32_t* __restrict__ dyn_cnt) {
     constexpr int D = KS * 16;
     constexpr int NT = 64 * NW;
     constexpr int STRIDE = D / 2 + 4;          // dwords per image row: the 4 spare dwords keep the 16-byte
@@ -100,6 +107,17 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     __shared__ __attribute__((aligned(8))) float rowc[NSLOT][32][2];   // per row: scale, shift (see below)
     __shared__ uint32_t hit_q[2][NW][MODE == 1 ? HITS : 1], hit_row[2][NW][MODE == 1 ? HITS : 1], hit_v[2][NW][MODE == 1 ? HITS : 1];
     __shared__ uint32_t hit_n[2][NW];   // entries in each list (written back by its wave at the end of every tile)
+    // MODE 1, the thresholds of the workgroup's queries. They tighten during the pass (trag_device.h:
+    // dyn_hit_level): wave 0 counts the hits it moves to memory for the levels of each query's ladder,
+    // raises the query's level in memory when `need` rows vouch for it, and on the same trip re-reads
+    // the levels of all the workgroup's queries (other workgroups raise them too) and brings this table
+    // up to date; every wave takes its thresholds from the table at the start of a tile. (No barrier orders the table's writes and reads: every value a threshold ever
+    // had is a valid one, a wave that reads an older one lists a few rows more.)
+    constexpr int QW = 32 * NW * QB;
+    __shared__ __attribute__((aligned(16))) float thr_lds[MODE == 1 ? QW : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t lvl_lds[MODE == 1 ? QW : 4];
+    __shared__ __attribute__((aligned(16))) float lad_lds[MODE == 1 ? QW : 4][2];
+    static_assert(QW == 4 * 64, "wave 0 keeps the table: four queries per lane");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
 
@@ -160,24 +178,43 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     auto qrow = [&](int rr) __attribute__((always_inline)) { return (uint32_t)((rr & 3) + 8 * (rr >> 2) + 4 * h); };
     constexpr int NA = 16 * QB;
     float th[NA];
-    if (MODE == 1) {
+    const uint32_t qg0 = g * (uint32_t)QW;   // first query of the workgroup
+    auto load_thresholds = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int rr = 0; rr < NA; ++rr) {
-            const uint32_t q = q0 + 32u * (uint32_t)(rr >> 4) + qrow(rr & 15);
-            th[rr] = q < n_queries ? thr[q] : INFINITY;
+        for (int blk = 0; blk < QB; ++blk)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const v4f x = *reinterpret_cast<const v4f*>(&thr_lds[wid * 32 * QB + 32 * blk + 8 * g4 + 4 * h]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) th[16 * blk + 4 * g4 + e] = x[e];
+            }
+    };
+    if (MODE == 1) {
+        if (tid < QW) {
+            // (the ladder arrays are padded to whole query groups: +inf behind the batch)
+            const uint32_t q = qg0 + (uint32_t)tid;
+            const uint32_t lv = dyn_lvl[q];
+            float t0 = dyn_lad[2 * q];
+            const float step = dyn_lad[2 * q + 1];
 #ifdef QS_EXP_NOHIT
-            th[rr] = INFINITY;
+            t0 = INFINITY;
 #endif
             // A query outside the bound's range (threshold -inf) would list every row: its list is
             // marked as overflowed once, here, and it takes no further part (the final stage reports
             // the overflow and the host repeats the query with the exact scan).
-            if (th[rr] == -INFINITY) {
-                if (strm == 0u && r == 0) atomicMax(&ctls[q].cand_count, CAND_CAP + 1u);
-                th[rr] = INFINITY;
+            if (t0 == -INFINITY) {
+                if (strm == 0u) atomicMax(&ctls[q].cand_count, CAND_CAP + 1u);
+                t0 = INFINITY;
             }
+            lvl_lds[tid] = lv;
+            lad_lds[tid][0] = t0;
+            lad_lds[tid][1] = step;
+            thr_lds[tid] = dyn_level_value(lv, t0, step);
         }
         if (tid < 2 * NW) hit_n[tid / NW][tid % NW] = 0u;
         drain_vmem();
+        __syncthreads();
+        load_thresholds();
     }
 
     // staging: the 32 rows of a subtile are one contiguous block of memory, cut into 16-byte pieces;
@@ -250,30 +287,65 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         hits_here = 0u;
     };
     auto flush = [&](int par) __attribute__((always_inline)) {
-        // (all the atomics first, then the stores that need their results: one round trip to memory
-        // for the whole flush instead of one per list -- wave 0 is stalled for that long, and at the
-        // tile's barrier so is everybody else)
-        uint32_t fq[NW], fpos[NW];
+        // The NW lists are taken as one sequence, 64 entries a round (a round is one round trip to
+        // memory -- wave 0 is stalled for that long, and at the tile's barrier so is everybody else):
+        // all the atomics first -- the list cursor and the counters of the ladder levels the row
+        // vouches for above the level the table knows -- then the stores that need their results.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // (see run_tile)
+        const uint32_t fill = ln < NW ? min(hit_n[par][ln], (uint32_t)HITS) : 0u;
+        uint32_t start[NW + 1];
+        start[0] = 0u;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const uint32_t n = min(hit_n[par][w], (uint32_t)HITS);
-            fq[w] = (uint32_t)lane < n ? hit_q[par][w][lane] : 0xFFFFFFFFu;
-        }
+        for (int w = 0; w < NW; ++w) start[w + 1] = start[w] + (uint32_t)__builtin_amdgcn_readlane((int)fill, w);
+        const uint32_t total = start[NW];
+        // (the queries' levels, as other workgroups have raised them meanwhile: the read travels with
+        // the atomics below)
+        const u32x4 lv = *reinterpret_cast<const u32x4*>(&dyn_lvl[qg0 + 4u * (uint32_t)ln]);
+        const uint32_t* hq = &hit_q[par][0][0];
+        const uint32_t* hr = &hit_row[par][0][0];
+        const uint32_t* hv = &hit_v[par][0][0];
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const uint32_t idx = base + (uint32_t)ln;
+            const bool valid = idx < total;
+            uint32_t w = 0u, s0 = 0u;
 #pragma unroll
-        for (int w = 0; w < NW; ++w)
-            fpos[w] = fq[w] != 0xFFFFFFFFu ? atomicAdd(&ctls[fq[w]].cand_count, 1u) : CAND_CAP;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            if (fpos[w] < CAND_CAP) {
-                cand[(size_t)fq[w] * CAND_CAP + fpos[w]] = hit_row[par][w][lane];
-                cvals[(size_t)fq[w] * CAND_CAP + fpos[w]] = hit_v[par][w][lane];
+            for (int ww = 1; ww < NW; ++ww) {
+                const bool ge = idx >= start[ww];
+                w = ge ? (uint32_t)ww : w;
+                s0 = ge ? start[ww] : s0;
             }
+            const uint32_t li = valid ? w * (uint32_t)HITS + (idx - s0) : 0u;
+            const uint32_t q = hq[li], row = hr[li], vbits = hv[li];
+            const uint32_t ql = valid ? q - qg0 : 0u;
+            const int jh = valid ? dyn_hit_level(__uint_as_float(vbits), lad_lds[ql][0], lad_lds[ql][1], (int)DYN_LEVELS, (int)DYN_SUB) : -1;
+            const int jlo = max((int)lvl_lds[ql], jh - (int)DYN_MAXINC);
+            uint32_t old[DYN_MAXINC];
+#pragma unroll
+            for (int i = 0; i < (int)DYN_MAXINC; ++i)
+                old[i] = (valid && jh - i > jlo) ? atomicAdd(&dyn_cnt[(size_t)q * DYN_LEVELS + (uint32_t)(jh - i)], 1u) : 0xFFFFFFF0u;
+            const uint32_t pos = valid ? atomicAdd(&ctls[q].cand_count, 1u) : CAND_CAP;
+            if (pos < CAND_CAP) {
+                cand[(size_t)q * CAND_CAP + pos] = row;
+                cvals[(size_t)q * CAND_CAP + pos] = vbits;
+            }
+#pragma unroll
+            for (int i = 0; i < (int)DYN_MAXINC; ++i)
+                if (old[i] + 1u == need) atomicMax(&dyn_lvl[q], (uint32_t)(jh - i));
+        }
+        {
+            const int q4 = 4 * ln;
+            v4f t;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = dyn_level_value(lv[i], lad_lds[q4 + i][0], lad_lds[q4 + i][1]);
+            *reinterpret_cast<v4f*>(&thr_lds[q4]) = t;
+            *reinterpret_cast<u32x4*>(&lvl_lds[q4]) = lv;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane < NW) hit_n[par][lane] = 0u;
+        if (ln < NW) hit_n[par][ln] = 0u;
         drain_vmem();
     };
-    static_assert(HITS == 64, "one lane per list entry in flush(); a wave's hits of one round always fit an empty list");
+    static_assert(HITS == 64, "a wave's hits of one round always fit an empty list");
     // MODE 0: the largest value of each (query, subtile), as an ordered key
     auto epilogue = [&](const v16f (&acc)[QB], int sl, uint32_t idx) __attribute__((always_inline)) {
         const float2 rc = *reinterpret_cast<const float2*>(&rowc[sl][r][0]);
@@ -420,9 +492,21 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         if (MODE == 1) {
             hits_here = hit_n[half][wid];
             if (wid == 0) {
-                const uint32_t fill = lane < NW ? hit_n[half ^ 1][lane] : 0u;
-                if (__builtin_amdgcn_ballot_w64(fill >= (uint32_t)HITS / 4u) != 0ull) flush(half ^ 1);
+                // the other parity's lists -> memory, when they hold enough (nobody appends to them during
+                // this tile)
+                // (the lane index passes through an opaque move wherever wave 0 forms an address that is the
+                // same for every tile: hoisted out of the loop, such an address is one more value live across
+                // the whole step loop, which has no register to spare -- it would be spilled, and its reload is
+                // a vector-memory load whose wait drains every staging load of the wave)
+                int ln = lane;
+                asm volatile("" : "+v"(ln));
+                const uint32_t fill = ln < NW ? hit_n[half ^ 1][ln] : 0u;
+                uint32_t total = 0u;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) total += (uint32_t)__builtin_amdgcn_readlane((int)fill, w);
+                if (total >= (uint32_t)QS_FLUSH_MIN) flush(half ^ 1);
             }
+            load_thresholds();
         }
 #pragma unroll
         for (int j = 0; j < NF; ++j) fr[j] = frag(half * NSUB, j);
@@ -566,10 +650,14 @@ qs_rowc_kernel(const float* __restrict__ norm2, const uint32_t* __restrict__ dea
 // top `need` has v >= A - 2 eps. Keep those rows (and the rows whose v is +inf or NaN: rows
 // outside the bound's range, always scored exactly), drop the rest, and record the lowered
 // threshold for the final check. A list that overflowed is left alone (the final stage reports it).
+// The full pass may have raised the query's threshold along its ladder (trag_device.h): the rows
+// left out of the list are then only known to lie below that raised value, and the final check
+// must be made against it.
 template <int METRIC>
 __global__ void __launch_bounds__(1024)
 qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const uint32_t* __restrict__ cvals,
-                float* __restrict__ thr, uint32_t d) {
+                float* __restrict__ thr, uint32_t d, const uint32_t* __restrict__ dyn_lvl,
+                const float* __restrict__ dyn_lad) {
     __shared__ unsigned long long sk[CAND_CAP];
     __shared__ uint32_t rows[CAND_CAP];
     __shared__ uint32_t n_inf_sh, keep_sh;
@@ -578,6 +666,18 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     SearchCtl* ctl = ctls + y;
     const uint32_t C = ctl->cand_count;
     const uint32_t need = ctl->need;
+    const float na = ctl->na, na_sq = ctl->na_sq;
+    // score space (t: what the final check compares with) from v space (tv: what the pass compared with)
+    auto to_score = [&](float tv) { return METRIC == 0 ? tv / na : (METRIC == 1 ? tv - na_sq : tv); };
+    const uint32_t level = dyn_lvl[y];
+    float tv_cur = thr[y];
+    if (level > 0u) {
+        tv_cur = dyn_level_value(level, dyn_lad[2 * y], dyn_lad[2 * y + 1]);
+        if (tid == 0) {
+            ctl->t_key = score_key(to_score(tv_cur));
+            thr[y] = tv_cur;
+        }
+    }
     if (C > CAND_CAP || C <= need) return;
     uint32_t* cq = cand + (size_t)y * CAND_CAP;
     const uint32_t* vq = cvals + (size_t)y * CAND_CAP;
@@ -615,13 +715,13 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     if (F + need > C) return;   // fewer than `need` rows with a usable score: keep the whole list
     const float A = key_score((uint32_t)(sk[F + need - 1] >> 32));
     // the lowered threshold, in score space (t, for the final check) and in v space (tv)
-    const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
+    const float vmax = sqrtf(ctl->vmax_sq);
     const float eps = bf16_eps<METRIC>(d, na, vmax);
     float t, tv;
     if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
-    else if (METRIC == 1) { t = (A - ctl->na_sq) - 2.02f * eps; tv = t + ctl->na_sq; }
+    else if (METRIC == 1) { t = (A - na_sq) - 2.02f * eps; tv = t + na_sq; }
     else { t = A - 2.02f * eps; tv = t; }
-    if (!(t == t) || !(tv == tv) || !(tv > thr[y])) return;   // nothing gained (or out of range): keep the list
+    if (!(t == t) || !(tv == tv) || !(tv > tv_cur)) return;   // nothing gained (or out of range): keep the list
     const uint32_t tkey = score_key(tv);
     // the survivors are a prefix of the sorted list
     uint32_t mine = 0;
@@ -644,6 +744,11 @@ bool qs_supports(uint32_t dim, uint32_t metric) {
 
 uint32_t qs_group_queries(uint32_t) { return 256u; }
 
+#ifndef QS_MAX_STEP
+#define QS_MAX_STEP 64
+#endif
+double bf16_step_by_list(uint32_t need, uint32_t dim);   // trag_bf16.hip
+
 // Most queries one pass takes: 8 query groups (the streams per XCD shrink with the groups).
 uint32_t qs_max_batch(uint32_t dim) { return 8u * qs_group_queries(dim); }
 
@@ -652,7 +757,7 @@ uint32_t qs_tile_rows(uint32_t) { return 64u; }
 
 template <int KS, int NW, int QB, int RT, int MODE, bool MIR, int DP, bool NTL>
 static void qs_launch_tile(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
-                          const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
+                          const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st) {
     static int cu_per_xcd = 0;
     if (cu_per_xcd == 0) {
         int dev = 0, n_cu = 256;
@@ -666,16 +771,17 @@ static void qs_launch_tile(uint32_t n_queries, const ScanArgs& a, const uint16_t
     const uint32_t grid = 8u * S * G;
     hipLaunchKernelGGL((qs_gemm_kernel<KS, NW, QB, RT, MODE, MIR, DP, NTL>), dim3(grid), dim3(64 * NW), 0, st, a.corpus,
                        d_mirror, reinterpret_cast<const __bf16*>(s.qb), s.rowc, a.n_rows, n_queries, G, S,
-                       tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys);
+                       tile_step, s.ctls, s.tmax, s.tmax_stride, s.cand, s.ckeys, need, s.dyn_lvl, s.dyn_lad,
+                       s.dyn_cnt);
 }
 
 // The corpus is read by G workgroups of one XCD: keep it in L2 for them; a single reader (one
 // query group) streams past the caches with non-temporal loads.
 template <int KS, int NW, int QB, int RT, int MODE, bool MIR, int DP>
 static void qs_launch_one(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
-                          const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
-    if (n_queries <= 32u * NW * QB) qs_launch_tile<KS, NW, QB, RT, MODE, MIR, DP, true>(n_queries, a, d_mirror, d_norm2, s, tile_step, st);
-    else qs_launch_tile<KS, NW, QB, RT, MODE, MIR, DP, false>(n_queries, a, d_mirror, d_norm2, s, tile_step, st);
+                          const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st) {
+    if (n_queries <= 32u * NW * QB) qs_launch_tile<KS, NW, QB, RT, MODE, MIR, DP, true>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st);
+    else qs_launch_tile<KS, NW, QB, RT, MODE, MIR, DP, false>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st);
 }
 
 #ifndef QS_DP_A
@@ -683,42 +789,40 @@ static void qs_launch_one(uint32_t n_queries, const ScanArgs& a, const uint16_t*
 #endif
 template <int MODE, bool MIR>
 static void qs_launch(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
-                      const Bf16Scratch& s, uint32_t tile_step, hipStream_t st) {
+                      const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st) {
     switch (a.dim) {
-    case 128: qs_launch_one<8, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, st); break;
-    case 256: qs_launch_one<16, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, st); break;
-    case 384: qs_launch_one<24, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, st); break;
+    case 128: qs_launch_one<8, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st); break;
+    case 256: qs_launch_one<16, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st); break;
+    case 384: qs_launch_one<24, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st); break;
     default: break;   // (qs_supports: the caller never comes here with another dimension)
     }
 }
 
-// Tiles between two sampled tiles. As bf16_sample_step, but the lists may be longer (the prune
-// stage shortens them before anything is re-scored): expected length need * step * w <= 1024.
+// Tiles between two sampled tiles. As bf16_sample_step; the lists may be longer here (the prune
+// stage shortens them before anything is re-scored), and the sample sparser: a pass over a 64th
+// of the tiles still gives every workgroup a few.
 uint32_t qs_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
     const uint64_t n_sub = (n_rows + 31) / 32;
     if (need == 0) need = 1;
     uint64_t step = n_sub / (64ull * need);   // the sample must hold many more 32-row groups than rows wanted
-    const double fd = (double)dim;
-    const double eps = 0.0078125 * 1.003 + fd * 2.3841858e-07 * 1.01 + (2.0 * fd + 64.0) * 5.9604645e-08;
-    const double w = std::exp(10.0 * eps * std::sqrt(fd));
-    const double by_list = 1024.0 / ((double)need * w);
+    const double by_list = bf16_step_by_list(need, dim);
     if ((double)step > by_list) step = (uint64_t)by_list;
-    return (uint32_t)(step < 1 ? 1 : (step > 16 ? 16 : step));
+    return (uint32_t)(step < 1 ? 1 : (step > QS_MAX_STEP ? QS_MAX_STEP : step));
 }
 
 // declared in trag_bf16.hip
 void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padded, uint32_t dim, uint16_t* qb,
                             hipStream_t st);
-void launch_shift_threshold(uint32_t metric, SearchCtl* ctls, uint32_t n_queries, uint32_t dim, float* thr,
+void launch_shift_threshold(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t padded, uint32_t dim,
                             hipStream_t st);
 
 void launch_qs_prune(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t dim, hipStream_t st) {
     if (metric == TRAG_COSINE)
-        hipLaunchKernelGGL(qs_prune_kernel<0>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim);
+        hipLaunchKernelGGL(qs_prune_kernel<0>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
     else if (metric == TRAG_EUCLIDEAN)
-        hipLaunchKernelGGL(qs_prune_kernel<1>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim);
+        hipLaunchKernelGGL(qs_prune_kernel<1>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
     else
-        hipLaunchKernelGGL(qs_prune_kernel<2>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim);
+        hipLaunchKernelGGL(qs_prune_kernel<2>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
 }
 
 // The whole prefilter for up to qs_max_batch(dim) queries: sample pass, thresholds, full pass, prune.
@@ -735,14 +839,14 @@ hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& 
     }
     const uint32_t step = qs_sample_step(a.n_rows, need, a.dim);
     const uint32_t RT = qs_tile_rows(a.dim);
-    if (d_mirror) qs_launch<0, true>(n_queries, a, d_mirror, d_norm2, s, step, st);
-    else qs_launch<0, false>(n_queries, a, d_mirror, d_norm2, s, step, st);
+    if (d_mirror) qs_launch<0, true>(n_queries, a, d_mirror, d_norm2, s, step, need, st);
+    else qs_launch<0, false>(n_queries, a, d_mirror, d_norm2, s, step, need, st);
     const uint32_t n_tiles = (a.n_rows + RT - 1) / RT;
     const uint32_t sampled = (n_tiles + step - 1) / step;
     launch_tau_select(s.tmax, s.tmax_stride, sampled * (RT / 32), s.ctls, n_queries, st);
-    launch_shift_threshold(a.metric, s.ctls, n_queries, a.dim, s.thr, st);
-    if (d_mirror) qs_launch<1, true>(n_queries, a, d_mirror, d_norm2, s, 1, st);
-    else qs_launch<1, false>(n_queries, a, d_mirror, d_norm2, s, 1, st);
+    launch_shift_threshold(a.metric, s, n_queries, padded, a.dim, st);
+    if (d_mirror) qs_launch<1, true>(n_queries, a, d_mirror, d_norm2, s, 1, need, st);
+    else qs_launch<1, false>(n_queries, a, d_mirror, d_norm2, s, 1, need, st);
     launch_qs_prune(a.metric, s, n_queries, a.dim, st);
     return hipGetLastError();
 }
