@@ -60,7 +60,7 @@ struct trag_store {
     uint64_t n_live = 0;
     uint32_t* d_dead = nullptr;    // bitmap, (cap_rows + 31) / 32 words
     std::vector<uint32_t> h_dead;  // host mirror
-    float* d_vmax_sq = nullptr;    // 1 float
+    float* d_vmax_sq = nullptr;    // 2 floats: largest squared row norm, largest squared bf16 rounding ratio of a row
     float* d_norm2 = nullptr;      // cap_rows squared row norms (batched cosine epilogue)
     uint16_t* d_mirror = nullptr;  // optional bf16 copy of d_rows (cap_rows x dim), kept in step with it
     BatchScratch batch{};
@@ -831,8 +831,8 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
     e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete s; return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
     e = hipEventCreateWithFlags(&s->order_ev, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc(&s->d_vmax_sq, sizeof(float));
-    if (e == hipSuccess) e = hipMemsetAsync(s->d_vmax_sq, 0, sizeof(float), s->stream);
+    if (e == hipSuccess) e = hipMalloc(&s->d_vmax_sq, 2 * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(s->d_vmax_sq, 0, 2 * sizeof(float), s->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(s->stream);
     if (e != hipSuccess) { trag_store_destroy(s); return fail(TRAG_DEVICE_ERROR, hipGetErrorString(e)); }
     if (cfg->reserve_rows) {
@@ -1263,7 +1263,7 @@ trag_status trag_store_clone(trag_store* src, trag_store** out) {
                                dst->stream);
     }
     if (e == hipSuccess)
-        e = hipMemcpyAsync(dst->d_vmax_sq, src->d_vmax_sq, sizeof(float), hipMemcpyDeviceToDevice, dst->stream);
+        e = hipMemcpyAsync(dst->d_vmax_sq, src->d_vmax_sq, 2 * sizeof(float), hipMemcpyDeviceToDevice, dst->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(dst->stream);
     if (e != hipSuccess) return give_up(fail(TRAG_DEVICE_ERROR, std::string("clone: ") + hipGetErrorString(e)));
     std::copy(src->h_dead.begin(), src->h_dead.begin() + std::min(src->h_dead.size(), dst->h_dead.size()),

@@ -23,14 +23,20 @@ __global__ void __launch_bounds__(256)
 prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict__ ctls,
                   uint32_t need, uint32_t k, const float* __restrict__ vmax_sq) {
     __shared__ __attribute__((aligned(16))) float qs[4096];
+    __shared__ float err_sh[4];
     const int tid = threadIdx.x;
     const float* q = Q + (size_t)blockIdx.x * d;
     SearchCtl* ctl = ctls + blockIdx.x;
     float acc = 0.0f;
+    float e2 = 0.0f;   // sum of (bf16(q) - q)^2, for the bf16 prefilter's bound (any order)
     for (uint32_t base = 0; base < d; base += 4096) {
         const uint32_t len = min(4096u, d - base);
         __syncthreads();
-        for (uint32_t i = tid; i < len; i += 256) qs[i] = q[base + i];
+        for (uint32_t i = tid; i < len; i += 256) {
+            const float x = q[base + i];
+            qs[i] = x;
+            e2 = bf16_round_err_sq(x, e2);
+        }
         __syncthreads();
         if (tid == 0) {
             uint32_t i = 0;
@@ -48,10 +54,15 @@ prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict
             }
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e2 += __shfl_xor(e2, o);
+    if ((tid & 63) == 0) err_sh[tid >> 6] = e2;
+    __syncthreads();
     if (tid == 0) {
         ctl->na_sq = acc;
         ctl->na = sqrtf(acc);
-        ctl->vmax_sq = vmax_sq ? *vmax_sq : 0.0f;
+        ctl->vmax_sq = vmax_sq ? vmax_sq[0] : 0.0f;
+        ctl->rho = bf16_operand_rho((err_sh[0] + err_sh[1]) + (err_sh[2] + err_sh[3]), acc, vmax_sq ? vmax_sq[1] : 1.0f);
         ctl->need = need;
         ctl->k = k;
         ctl->resolved = 1;  // the threshold comes from tau_select_kernel, not from histograms

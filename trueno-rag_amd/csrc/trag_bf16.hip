@@ -74,7 +74,7 @@ __global__ void shift_threshold_kernel(SearchCtl* __restrict__ ctls, uint32_t n_
         const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
         const bool in_range = na * vmax < 1e30f && (METRIC != 0 || na > 0.0f);  // false for NaN too
         if (tk >= 0x007FFFFFu && in_range) {
-            const float eps = bf16_eps<METRIC>(d, na, vmax);
+            const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
             const float tv = key_score(tk);
             if (METRIC == 0) { t = tv / na - 2.02f * eps; v = t * na; step = 2.02f * eps * na; }
             else if (METRIC == 1) { t = (tv - ctl->na_sq) - 2.02f * eps; v = t + ctl->na_sq; step = 2.02f * eps; }

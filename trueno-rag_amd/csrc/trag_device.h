@@ -45,15 +45,41 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // bf16 prefilter: largest |approximate - reference| of a score, as a multiple of
-// the scale ||q|| * ||v|| (cosine: of 1). bf16 keeps 8 significant bits, so rounding
-// to nearest moves a value by at most 2^-8 of its magnitude; with both operands
-// rounded, Cauchy-Schwarz gives |sum q'v' - sum qv| <= (2 * 2^-8 + 2^-16) ||q|| ||v||.
+// the scale ||q|| * ||v|| (cosine: of 1). With q' and v' the operands rounded to bf16,
+//   |sum q'v' - sum qv| = |q'.(v' - v) + (q' - q).v| <= ||q'|| ||v' - v|| + ||q' - q|| ||v||
+//                       <= (rho_q + rho_v + rho_q rho_v) ||q|| ||v||,
+// rho_q = ||q' - q|| / ||q|| of this query and rho_v the largest ||v' - v|| / ||v|| over the
+// corpus rows. Both are MEASURED, not assumed: the differences x' - x are exact in f32, the
+// store keeps the largest squared ratio of its rows beside the largest squared norm (updated
+// by every insert, never lowered) and the batch prep measures each query (bf16_operand_rho).
+// bf16 keeps 8 significant bits, so the worst case is 2^-8 each (a vector whose every
+// component sits just below a rounding boundary); embeddings measure near 0.4 * 2^-8, which
+// makes the bound -- and with it the candidate lists -- 2.5 times tighter.
 // Added to it: d f32 accumulation steps of unknown rounding inside the matrix cores
 // (2^-22 each) and the rounding of the reference's own sequential sum and norms
 // ((2d + 64) * 2^-24).
-__device__ __forceinline__ float bf16_unit_eps(uint32_t d) {
+__device__ __forceinline__ float bf16_unit_eps(uint32_t d, float rho) {
     const float fd = (float)d;
-    return (0.0078125f * 1.003f + fd * 2.3841858e-07f * 1.01f + (2.0f * fd + 64.0f) * 5.9604645e-08f) * 1.01f;
+    return (rho * 1.003f + fd * 2.3841858e-07f * 1.01f + (2.0f * fd + 64.0f) * 5.9604645e-08f) * 1.01f;
+}
+
+// rho of a query against a store. eq2 = sum (q' - q)^2 and na_sq = sum q^2 (any summation
+// order: 1 % covers their rounding), rho_v_sq = the store's largest squared ratio (already
+// inflated). Anything out of range: the format's worst case.
+__device__ __forceinline__ float bf16_operand_rho(float eq2, float na_sq, float rho_v_sq) {
+    const float worst = 2.0f * 0.00390625f + 1.52587890625e-05f;
+    float rq = 0.0f;   // (a zero query has q' = q)
+    if (na_sq > 0.0f) rq = sqrtf(eq2 / na_sq * 1.01f);
+    const float rv = sqrtf(rho_v_sq);
+    const float r = (rq + rv + rq * rv) * 1.001f;
+    return (r >= 0.0f && r < worst) ? r : worst;
+}
+
+// sum over the components of (bf16(x) - x)^2, one component: the rounding is the matrix-core
+// kernels' (and the mirror's) own conversion, the difference is exact
+__device__ __forceinline__ float bf16_round_err_sq(float x, float acc) {
+    const float r = (float)(__bf16)x - x;
+    return __builtin_fmaf(r, r, acc);
 }
 
 // Single-query scan of the bf16 mirror: only the corpus is rounded (the query stays
@@ -74,8 +100,8 @@ __device__ __forceinline__ float mirror_eps(uint32_t d, float na, float vmax) {
 // The same bound in the key space of each metric (0 cosine: score; 2 dot
 // product: score; 1 Euclidean: negated squared distance).
 template <int METRIC>
-__device__ __forceinline__ float bf16_eps(uint32_t d, float na, float vmax) {
-    const float c = bf16_unit_eps(d);
+__device__ __forceinline__ float bf16_eps(uint32_t d, float na, float vmax, float rho) {
+    const float c = bf16_unit_eps(d, rho);
     if (METRIC == 0) return c + 1e-30f;
     if (METRIC == 2) return c * na * vmax + 1e-30f;
     const float span = na + vmax;

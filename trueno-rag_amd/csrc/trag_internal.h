@@ -55,6 +55,7 @@ struct SearchCtl {
     uint32_t levels;     // radix levels the last select needed (diagnostics)
     uint32_t n_waves;    // waves of the scan grid: tile t was scanned by wave t % n_waves
     uint32_t keep_key;   // sparse key stores: the bound the select raised its cut to (0: none; diagnostics)
+    float rho;           // bf16 prefilter: measured relative rounding error of the operands (trag_device.h: bf16_operand_rho)
 };
 
 // Device scratch of one in-flight query.
@@ -88,7 +89,7 @@ struct BatchScratch {
 // bf16 prefilter, thresholds that tighten during the full pass (trag_device.h: dyn_hit_level).
 // Every query has a ladder of DYN_LEVELS thresholds, DYN_SUB steps per 2.02 eps, above the one its
 // sample gave; a hit is counted for at most DYN_MAXINC levels.
-constexpr uint32_t DYN_LEVELS = 32;
+constexpr uint32_t DYN_LEVELS = 64;
 constexpr uint32_t DYN_SUB = 4;
 constexpr uint32_t DYN_MAXINC = 4;
 

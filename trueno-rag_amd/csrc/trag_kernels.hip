@@ -731,6 +731,7 @@ __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float
     const float steps = ((key_mode == 1 || key_mode == 2) ? 5.0f : 2.0f) + (METRIC == 0 ? 1.0f : 0.0f);
     float eps = (steps * (float)d + 64.0f) * u;
     const float vmax = sqrtf(ctl->vmax_sq);
+    const float rho = ctl->rho;
     // the bound assumes ||q||^2 is a normal number well inside the f32 range
     const float nsq = ctl->na_sq;
     if (!(nsq == 0.0f || (nsq >= 0x1p-100f && nsq < 0x1p100f))) status = ST_UNCERTIFIED;
@@ -741,13 +742,13 @@ __device__ uint32_t certify(const SearchCtl* __restrict__ ctl, uint32_t d, float
         // distance >= T2 = -t; the exact k-th distance (squared, plus the rounding of the
         // exact path) must stay below T2 minus that error.
         const float span = na + vmax;
-        const float eps2 = key_mode == 3 ? bf16_eps<1>(d, na, vmax) : eps * span * span * 1.01f + 1e-30f;
+        const float eps2 = key_mode == 3 ? bf16_eps<1>(d, na, vmax, rho) : eps * span * span * 1.01f + 1e-30f;
         const float T2 = -t;
         const float dk2 = ek * ek * (1.0f + eps);
         if (!(dk2 + eps2 < T2) || !(eps2 < INFINITY)) status = ST_UNCERTIFIED;
         return status;
     }
-    if (key_mode == 3) eps = bf16_eps<METRIC>(d, na, vmax);
+    if (key_mode == 3) eps = bf16_eps<METRIC>(d, na, vmax, rho);
     else if (key_mode == 4) eps = mirror_eps<METRIC>(d, na, vmax);
     else if (METRIC == 2) eps = eps * na * vmax * 1.01f + 1e-30f;
     else if (METRIC == 1) eps = eps * (na + vmax) * 1.01f + 1e-20f;
@@ -1634,27 +1635,39 @@ synth_fill_kernel(unsigned long long seed, unsigned long long row0, unsigned lon
 }
 
 // Upper bound of max over rows of sum v*v (any summation order; inflated by
-// 1e-3). One wave per row, coalesced.
+// 1e-3) into vmax_sq[0], and of max over rows of ||bf16(v) - v||^2 / ||v||^2 (inflated by
+// 1 %; rows whose norm is outside the bf16 bound's range are left out: they are candidates
+// whatever their approximate score) into vmax_sq[1]. One wave per row, coalesced.
 __global__ void __launch_bounds__(256)
 vmax_kernel(const float* __restrict__ rows, unsigned long long n, uint32_t d,
             float* __restrict__ vmax_sq, float* __restrict__ norm2_out) {
     const int lane = threadIdx.x & 63;
     const unsigned long long w0 = ((unsigned long long)blockIdx.x * 256ull + threadIdx.x) >> 6;
     const unsigned long long nw = ((unsigned long long)gridDim.x * 256ull) >> 6;
-    float best = 0.0f;
+    float best = 0.0f, best_rho = 0.0f;
     for (unsigned long long r = w0; r < n; r += nw) {
         const float* v = rows + r * d;
-        float s = 0.0f;
-        for (uint32_t c = lane; c < d; c += 64) s = __builtin_fmaf(v[c], v[c], s);
+        float s = 0.0f, e2 = 0.0f;
+        for (uint32_t c = lane; c < d; c += 64) {
+            const float x = v[c];
+            s = __builtin_fmaf(x, x, s);
+            e2 = bf16_round_err_sq(x, e2);
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            e2 += __shfl_xor(e2, o);
+        }
         if (lane == 0 && norm2_out) norm2_out[r] = s;  // squared norm, reassociated sum
+        if (s >= 0x1p-100f && s < INFINITY) best_rho = fmaxf(best_rho, e2 / s * 1.01f);  // (fmaxf drops a NaN)
         s = s * 1.001f;
         if (!(s < INFINITY)) continue;  // non-finite rows are always re-scored exactly
         best = fmaxf(best, s);
     }
     if (lane == 0 && best > 0.0f)
         atomicMax(reinterpret_cast<unsigned int*>(vmax_sq), __float_as_uint(best));
+    if (lane == 0 && best_rho > 0.0f)
+        atomicMax(reinterpret_cast<unsigned int*>(vmax_sq) + 1, __float_as_uint(best_rho));
 }
 
 // Reference point for the roofline figures: a plain contiguous stream over the same memory,

@@ -678,6 +678,9 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
             thr[y] = tv_cur;
         }
     }
+#ifdef QS_DIAG
+    if (tid == 0 && (y & 63u) == 0u) printf("query %u: list %u, level %u\n", y, C, level);
+#endif
     if (C > CAND_CAP || C <= need) return;
     uint32_t* cq = cand + (size_t)y * CAND_CAP;
     const uint32_t* vq = cvals + (size_t)y * CAND_CAP;
@@ -716,7 +719,7 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     const float A = key_score((uint32_t)(sk[F + need - 1] >> 32));
     // the lowered threshold, in score space (t, for the final check) and in v space (tv)
     const float vmax = sqrtf(ctl->vmax_sq);
-    const float eps = bf16_eps<METRIC>(d, na, vmax);
+    const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
     float t, tv;
     if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
     else if (METRIC == 1) { t = (A - na_sq) - 2.02f * eps; tv = t + na_sq; }

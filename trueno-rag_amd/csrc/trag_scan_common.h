@@ -50,6 +50,7 @@ __device__ __forceinline__ void publish_ctl(SearchCtl* __restrict__ ctl, float n
     ctl->vmax_sq = vmax_sq ? *vmax_sq : 0.0f;
     ctl->need = need;
     ctl->k = k;
+    ctl->rho = 0.0f;   // (only the bf16 prefilter's batch prep measures it)
 }
 
 // ---------------------------------------------------------------------------
