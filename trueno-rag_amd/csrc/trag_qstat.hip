@@ -30,9 +30,12 @@
 #include "trag_device.h"
 #include "trag_internal.h"
 
-// Entries the lists of one tile parity must hold together before wave 0 moves them to memory.
+// Entries the lists of one tile parity must hold together before wave 0 moves them to memory: the
+// move stalls wave 0 for a round trip to memory, and the other waves at the tile's barrier; what a
+// later move costs is thresholds that lag (1.25 M x 384 x 1000 queries, ms per step on one device:
+// 8 entries 1.323, 16 1.299, 32 1.288; with the tighter bound 16 1.260, 48 1.232).
 #ifndef QS_FLUSH_MIN
-#define QS_FLUSH_MIN 16
+#define QS_FLUSH_MIN 48
 #endif
 
 namespace trag {
@@ -653,8 +656,11 @@ qs_rowc_kernel(const float* __restrict__ norm2, const uint32_t* __restrict__ dea
 // The full pass may have raised the query's threshold along its ladder (trag_device.h): the rows
 // left out of the list are then only known to lie below that raised value, and the final check
 // must be made against it.
+// (256 threads: the lists are a few hundred entries long, and four times as many workgroups fit a CU as
+// with 1024 -- what the stage costs is the latency of its loads and barriers, not its work.)
+constexpr int PRUNE_THREADS = 256;
 template <int METRIC>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(PRUNE_THREADS)
 qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const uint32_t* __restrict__ cvals,
                 float* __restrict__ thr, uint32_t d, const uint32_t* __restrict__ dyn_lvl,
                 const float* __restrict__ dyn_lad) {
@@ -678,7 +684,7 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
             thr[y] = tv_cur;
         }
     }
-#ifdef QS_DIAG
+#ifdef TRAG_LIST_DIAG
     if (tid == 0 && (y & 63u) == 0u) printf("query %u: list %u, level %u\n", y, C, level);
 #endif
     if (C > CAND_CAP || C <= need) return;
@@ -689,7 +695,7 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     if (tid == 0) { n_inf_sh = 0; keep_sh = 0; }
     __syncthreads();
     uint32_t n_inf = 0;
-    for (uint32_t i = tid; i < P; i += 1024u) {
+    for (uint32_t i = tid; i < P; i += (uint32_t)PRUNE_THREADS) {
         unsigned long long e = 0ull;
         if (i < C) {
             const float v = __uint_as_float(vq[i]);
@@ -705,7 +711,7 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     for (uint32_t size = 2; size <= P; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (uint32_t i = tid; i < P / 2; i += 1024u) {
+            for (uint32_t i = tid; i < P / 2; i += (uint32_t)PRUNE_THREADS) {
                 const uint32_t pos = 2 * i - (i & (stride - 1));
                 const unsigned long long a = sk[pos], b = sk[pos + stride];
                 const bool desc = (pos & size) == 0;
@@ -728,11 +734,11 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     const uint32_t tkey = score_key(tv);
     // the survivors are a prefix of the sorted list
     uint32_t mine = 0;
-    for (uint32_t i = tid; i < C; i += 1024u) mine += (uint32_t)(sk[i] >> 32) >= tkey;
+    for (uint32_t i = tid; i < C; i += (uint32_t)PRUNE_THREADS) mine += (uint32_t)(sk[i] >> 32) >= tkey;
     if (mine) atomicAdd(&keep_sh, mine);
     __syncthreads();
     const uint32_t keep = keep_sh;
-    for (uint32_t i = tid; i < keep; i += 1024u)
+    for (uint32_t i = tid; i < keep; i += (uint32_t)PRUNE_THREADS)
         cq[i] = rows[0xFFFFFFFFu - (uint32_t)(sk[i] & 0xFFFFFFFFull)];
     if (tid == 0) {
         ctl->cand_count = keep;
@@ -748,7 +754,10 @@ bool qs_supports(uint32_t dim, uint32_t metric) {
 uint32_t qs_group_queries(uint32_t) { return 256u; }
 
 #ifndef QS_MAX_STEP
-#define QS_MAX_STEP 64
+#define QS_MAX_STEP 128
+#endif
+#ifndef QS_SAMPLE_GROUPS
+#define QS_SAMPLE_GROUPS 16
 #endif
 double bf16_step_by_list(uint32_t need, uint32_t dim);   // trag_bf16.hip
 
@@ -802,12 +811,13 @@ static void qs_launch(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_m
 }
 
 // Tiles between two sampled tiles. As bf16_sample_step; the lists may be longer here (the prune
-// stage shortens them before anything is re-scored), and the sample sparser: a pass over a 64th
-// of the tiles still gives every workgroup a few.
+// stage shortens them before anything is re-scored), and the sample sparser: a pass over a 128th
+// of the tiles still gives every stream a tile or two (1.25 M x 384 x 1000 queries, ms per step on one
+// device: every 61st tile 1.260, every 122nd 1.242, every 244th 1.244).
 uint32_t qs_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
     const uint64_t n_sub = (n_rows + 31) / 32;
     if (need == 0) need = 1;
-    uint64_t step = n_sub / (64ull * need);   // the sample must hold many more 32-row groups than rows wanted
+    uint64_t step = n_sub / ((uint64_t)QS_SAMPLE_GROUPS * need);   // the sample must hold many more 32-row groups than rows wanted
     const double by_list = bf16_step_by_list(need, dim);
     if ((double)step > by_list) step = (uint64_t)by_list;
     return (uint32_t)(step < 1 ? 1 : (step > QS_MAX_STEP ? QS_MAX_STEP : step));
@@ -821,11 +831,11 @@ void launch_shift_threshold(uint32_t metric, const Bf16Scratch& s, uint32_t n_qu
 
 void launch_qs_prune(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t dim, hipStream_t st) {
     if (metric == TRAG_COSINE)
-        hipLaunchKernelGGL(qs_prune_kernel<0>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
+        hipLaunchKernelGGL(qs_prune_kernel<0>, dim3(n_queries), dim3(PRUNE_THREADS), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
     else if (metric == TRAG_EUCLIDEAN)
-        hipLaunchKernelGGL(qs_prune_kernel<1>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
+        hipLaunchKernelGGL(qs_prune_kernel<1>, dim3(n_queries), dim3(PRUNE_THREADS), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
     else
-        hipLaunchKernelGGL(qs_prune_kernel<2>, dim3(n_queries), dim3(1024), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
+        hipLaunchKernelGGL(qs_prune_kernel<2>, dim3(n_queries), dim3(PRUNE_THREADS), 0, st, s.ctls, s.cand, s.ckeys, s.thr, dim, s.dyn_lvl, s.dyn_lad);
 }
 
 // The whole prefilter for up to qs_max_batch(dim) queries: sample pass, thresholds, full pass, prune.
