@@ -134,8 +134,21 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     // a few MFMAs after the last and its registers at once reloaded for the step after next, so that
     // the loads in flight never drop to zero; counted waits, no spills in the loop -- measured slower:
     // full pass over 1M x 768 f32 rows, 256 queries, 0.70 ms against 0.64. The same bytes are in
-    // flight either way (one step per thread); what the pass lacks is bytes in flight, or a friendlier
-    // pattern than 256 bytes from each of 256 rows per step, not the gap while it stages.)
+    // flight either way (one step per thread), and the gap while it stages is not what the pass lacks.)
+    // (Neither is it the access pattern or the bytes in flight: a probe that reads 256 bytes from each of
+    // the tile's rows per step, with the query slab and the LDS writes beside it, streams at 6.7-7.1 TB/s
+    // with ONE step in flight -- scripts/diag_slab.hip. A wave-specialised form was built to find out
+    // what it is: 256 queries x 128 rows, four producer waves that only stream the f32 corpus (four
+    // k-steps deep in registers -> bf16 -> LDS), four consumer waves that bring the query slab in by
+    // direct-to-LDS transfers two steps ahead and issue all the MFMAs, two / three LDS stages, one
+    // barrier per step, persistent over the tiles so that nothing drains at a tile's end. Bit-identical
+    // results; full pass over 1M x 768, 256 queries: 0.73 ms against this kernel's 0.64-0.66. Taken
+    // apart on the same device (no hits listed in any of these): corpus stream + conversion + fragment
+    // reads alone 0.47 ms -- HBM's rate --, + the query transfers 0.57, + the MFMAs instead 0.59, both
+    // 0.71, + the hits 0.76. The pieces ADD instead of overlapping: every one of them is far from its
+    // own limit (matrix pipe 25-45 %, LDS and the vector-memory path about half), but each k-step
+    // strings them together through its barrier -- transfers landed, stage written, fragments read,
+    // MFMAs issued, by in-order waves -- and what a step cannot hide it pays in full.)
     constexpr int BM = 32 * TM * WGM;   // queries per workgroup tile
     constexpr int BN = 64 * WGN;        // corpus rows per workgroup tile
     constexpr int NLA = BM * 8 / NT;    // 16-byte chunks of the query tile per thread and step
@@ -151,7 +164,10 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     // by then (trag_device.h: dyn_level_value), and its hits are counted for the levels above it
     __shared__ float qs_lad[MODE == 1 ? BM : 1][2];
     __shared__ uint32_t qs_lvl[MODE == 1 ? BM : 1];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (the wave's number as a scalar: what is derived from it -- LDS addresses of the wave's part of a
+    // tile, the M0 values of the direct-to-LDS transfers -- then lives in scalar registers)
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid / WGN, wn = wid % WGN;
 
     // workgroups sharing a corpus tile (different query tiles) are adjacent on one XCD
