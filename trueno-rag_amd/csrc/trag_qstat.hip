@@ -526,7 +526,9 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
             const uint32_t row0_issue = unit[it] * rows_per_unit + 32u * (uint32_t)isub;
 #ifdef QS_PRIO
             // the two waves of a SIMD take turns at being preferred by the issue arbiter (which, left
-            // alone, always prefers the older one: waves 0..3)
+            // alone, always prefers the older one: waves 0..3). (Measured without effect, as was one
+            // s_setprio 1 for waves 4..7 before the tile loop: 1.196 / 1.197 ms per step without, 1.202 /
+            // 1.191 with, 1.25 M x 384 x 1000 queries.)
             if (NW == 8) {
                 if ((wid >= 4) == ((sub & 1) != 0)) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
