@@ -17,16 +17,14 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int BT_KMIN = 32;      // dimensions must be a multiple of this
 
-// prep for a block of queries: one workgroup per query computes ||q|| in the
-// reference's order and resets that query's control block.
-__global__ void __launch_bounds__(256)
-prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict__ ctls,
-                  uint32_t need, uint32_t k, const float* __restrict__ vmax_sq) {
+// prep for one query, by one workgroup of 256 threads: ||q|| in the reference's order, the query's
+// control block reset, and (qb_row != nullptr) the query converted to bf16 for the prefilter.
+__device__ __forceinline__ void prep_query(const float* __restrict__ q, uint32_t d, SearchCtl* __restrict__ ctl,
+                                           uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
+                                           __bf16* __restrict__ qb_row) {
     __shared__ __attribute__((aligned(16))) float qs[4096];
     __shared__ float err_sh[4];
     const int tid = threadIdx.x;
-    const float* q = Q + (size_t)blockIdx.x * d;
-    SearchCtl* ctl = ctls + blockIdx.x;
     float acc = 0.0f;
     float e2 = 0.0f;   // sum of (bf16(q) - q)^2, for the bf16 prefilter's bound (any order)
     for (uint32_t base = 0; base < d; base += 4096) {
@@ -36,6 +34,7 @@ prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict
             const float x = q[base + i];
             qs[i] = x;
             e2 = bf16_round_err_sq(x, e2);
+            if (qb_row) qb_row[base + i] = (__bf16)x;
         }
         __syncthreads();
         if (tid == 0) {
@@ -74,6 +73,37 @@ prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict
         ctl->expect = 0;
         ctl->cand_count = 0;
         ctl->status = ST_OK;
+    }
+}
+
+// prep for a block of queries: one workgroup per query.
+__global__ void __launch_bounds__(256)
+prep_batch_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict__ ctls,
+                  uint32_t need, uint32_t k, const float* __restrict__ vmax_sq) {
+    prep_query(Q + (size_t)blockIdx.x * d, d, ctls + blockIdx.x, need, k, vmax_sq, nullptr);
+}
+
+// Everything the bf16 prefilter needs before its first pass, in one launch (three small launches in
+// a row cost their latencies one after the other; here the per-row constants fill the chip while
+// the query workgroups wait for the one thread that sums in the reference's order). Workgroups
+// [0, n_queries): prep_query, which also writes the query's bf16 image; [n_queries, padded): zero
+// rows behind the batch (the passes read whole query groups); the rest, if rowc != nullptr: (scale,
+// shift) of every row up to n_pad, the next multiple of 64 rows (the query-stationary pass reads that far).
+__global__ void __launch_bounds__(256)
+bf16_prep_kernel(const float* __restrict__ Q, uint32_t d, SearchCtl* __restrict__ ctls, uint32_t need, uint32_t k,
+                 const float* __restrict__ vmax_sq, uint32_t n_queries, uint32_t padded, __bf16* __restrict__ qb,
+                 const float* __restrict__ norm2, const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t n_pad,
+                 uint32_t metric, float2* __restrict__ rowc) {
+    const uint32_t b = blockIdx.x;
+    if (b < n_queries) {
+        prep_query(Q + (size_t)b * d, d, ctls + b, need, k, vmax_sq, qb + (size_t)b * d);
+    } else if (b < padded) {
+        __bf16* row = qb + (size_t)b * d;
+        for (uint32_t i = threadIdx.x; i < d; i += 256) row[i] = (__bf16)0.0f;
+    } else {
+        const uint32_t nb = gridDim.x - padded;
+        for (uint32_t row = (b - padded) * 256u + threadIdx.x; row < n_pad; row += nb * 256u)
+            rowc[row] = row_scale_shift(norm2, dead, n_rows, metric, row);
     }
 }
 
@@ -381,10 +411,15 @@ pad_queries_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t pad
     }
 }
 
-hipError_t launch_batch_prep(const float* d_Q, uint32_t n_queries, uint32_t dim, SearchCtl* ctls,
-                             uint32_t need, uint32_t k, const float* d_vmax_sq, hipStream_t st) {
-    hipLaunchKernelGGL(prep_batch_kernel, dim3(n_queries), dim3(256), 0, st, d_Q, dim, ctls, need, k,
-                       d_vmax_sq);
+// with_rowc: also the per-row (scale, shift) table of the query-stationary pass.
+hipError_t launch_bf16_prep(const float* d_Q, uint32_t n_queries, uint32_t padded, const ScanArgs& a,
+                            const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
+                            const float* d_vmax_sq, bool with_rowc, hipStream_t st) {
+    const uint32_t n_pad = (a.n_rows + 63u) / 64u * 64u;
+    const uint32_t row_groups = with_rowc ? std::min<uint32_t>((n_pad + 255u) / 256u, 2048u) : 0u;
+    hipLaunchKernelGGL(bf16_prep_kernel, dim3(padded + row_groups), dim3(256), 0, st, d_Q, a.dim, s.ctls, need, k,
+                       d_vmax_sq, n_queries, padded, reinterpret_cast<__bf16*>(s.qb), d_norm2, a.dead, a.n_rows, n_pad,
+                       a.metric, reinterpret_cast<float2*>(with_rowc ? s.rowc : nullptr));
     return hipGetLastError();
 }
 

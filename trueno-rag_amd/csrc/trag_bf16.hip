@@ -38,19 +38,6 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BF_K = 64;   // f32 columns staged per step (= 4 MFMA k-steps of 16)
 constexpr int BF_LD = 36;  // dwords per LDS row: 64 bf16 + 4 dwords of padding (conflict-free b128 reads)
 
-// Queries -> bf16, zero-padded to `padded` rows.
-__global__ void __launch_bounds__(256)
-queries_to_bf16_kernel(const float* __restrict__ Q, uint32_t n_queries, uint32_t padded, uint32_t d,
-                       __bf16* __restrict__ out) {
-    const size_t total4 = (size_t)padded * d / 4;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (size_t)gridDim.x * 256) {
-        const size_t q = (e * 4) / d;
-        v4f x = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (q < n_queries) x = reinterpret_cast<const v4f*>(Q)[e];
-        reinterpret_cast<bf16x4*>(out)[e] = __builtin_convertvector(x, bf16x4);
-    }
-}
-
 // After tau_select on the sample's tile maxima, which are keys of the row-dependent part
 // v of the score (cosine v = dot * inv_nb = score * ||q||; dot product v = score;
 // Euclidean v = 2 dot - ||v||^2 = -(squared distance) + ||q||^2): lower each query's
@@ -560,13 +547,11 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
 #undef TRAG_LAUNCH_BF16
 }
 
-// prep (norms, control blocks) is done by the caller with launch_batch_prep.
+// The caller has run launch_bf16_prep (norms, control blocks, bf16 queries).
 template <int METRIC, bool MIR>
-static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+static void bf16_scan_metric(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
                              const float* d_norm2, const Bf16Scratch& s, uint32_t need, hipStream_t st) {
     const uint32_t padded = (n_queries + 255u) / 256u * 256u;
-    hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min<uint32_t>(1024, (padded * a.dim / 4 + 255) / 256)),
-                       dim3(256), 0, st, d_Q, n_queries, padded, a.dim, reinterpret_cast<__bf16*>(s.qb));
     const uint32_t step = bf16_sample_step(a.n_rows, need, a.dim);
     launch_gemm_bf16<METRIC, 0, MIR>(n_queries, a, d_mirror, d_norm2, s, step, need, st);
     // 64-row tiles the sample pass wrote maxima for (its last 128/256-row tile may be partial)
@@ -581,12 +566,6 @@ static void bf16_scan_metric(const float* d_Q, uint32_t n_queries, const ScanArg
     // the lists hold every row above the sample's threshold, with its approximate value: keep the
     // rows within 2 eps of the list's need-th largest value (trag_qstat.hip)
     launch_qs_prune(METRIC, s, n_queries, a.dim, st);
-}
-
-void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padded, uint32_t dim, uint16_t* qb,
-                            hipStream_t st) {
-    hipLaunchKernelGGL(queries_to_bf16_kernel, dim3(std::min<uint32_t>(1024, (padded * dim / 4 + 255) / 256)),
-                       dim3(256), 0, st, d_Q, n_queries, padded, dim, reinterpret_cast<__bf16*>(qb));
 }
 
 void launch_shift_threshold(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t padded, uint32_t dim,
@@ -625,17 +604,20 @@ uint32_t bf16_max_batch(uint32_t dim, uint32_t metric, uint32_t n_queries) {
 hipError_t launch_bf16_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
                             const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
                             const float* d_vmax_sq, hipStream_t st) {
-    hipError_t e = launch_batch_prep(d_Q, n_queries, a.dim, s.ctls, need, k, d_vmax_sq, st);
+    const bool qs = bf16_uses_qs(a.dim, a.metric, n_queries);
+    const uint32_t group = qs ? qs_group_queries(a.dim) : 256u;
+    hipError_t e = launch_bf16_prep(d_Q, n_queries, (n_queries + group - 1) / group * group, a, d_norm2, s, need, k,
+                                    d_vmax_sq, qs, st);
     if (e != hipSuccess) return e;
-    if (bf16_uses_qs(a.dim, a.metric, n_queries)) return launch_qs_scan(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+    if (qs) return launch_qs_scan(n_queries, a, d_mirror, d_norm2, s, need, st);
     if (d_mirror) {
-        if (a.metric == TRAG_COSINE) bf16_scan_metric<0, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
-        else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
-        else bf16_scan_metric<2, true>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+        if (a.metric == TRAG_COSINE) bf16_scan_metric<0, true>(n_queries, a, d_mirror, d_norm2, s, need, st);
+        else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1, true>(n_queries, a, d_mirror, d_norm2, s, need, st);
+        else bf16_scan_metric<2, true>(n_queries, a, d_mirror, d_norm2, s, need, st);
     } else {
-        if (a.metric == TRAG_COSINE) bf16_scan_metric<0, false>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
-        else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1, false>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
-        else bf16_scan_metric<2, false>(d_Q, n_queries, a, d_mirror, d_norm2, s, need, st);
+        if (a.metric == TRAG_COSINE) bf16_scan_metric<0, false>(n_queries, a, d_mirror, d_norm2, s, need, st);
+        else if (a.metric == TRAG_EUCLIDEAN) bf16_scan_metric<1, false>(n_queries, a, d_mirror, d_norm2, s, need, st);
+        else bf16_scan_metric<2, false>(n_queries, a, d_mirror, d_norm2, s, need, st);
     }
     return hipGetLastError();
 }

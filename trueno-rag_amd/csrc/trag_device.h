@@ -34,6 +34,26 @@ __device__ __forceinline__ bool row_is_dead(const uint32_t* __restrict__ dead, u
     return (dead[row >> 5] >> (row & 31)) & 1u;
 }
 
+// The row-dependent part of a score is v = fma(dot, scale, shift) -- cosine dot / ||v||, dot product
+// dot, Euclidean 2 dot - ||v||^2: (scale, shift) of one row for the bf16 prefilter's passes. Rows
+// that take no part (removed, past the end): scale 0, shift -inf. Rows whose norm is outside the
+// bound's range must always be candidates: scale 0, shift +inf (the sample pass leaves them out).
+// The reciprocal square root is the hardware's (1 ulp): v only has to be within the bound's 1 % slack
+// of its value.
+__device__ __forceinline__ float2 row_scale_shift(const float* __restrict__ norm2, const uint32_t* __restrict__ dead,
+                                                  uint32_t n_rows, uint32_t metric, uint32_t row) {
+    const bool live = row < n_rows && !row_is_dead(dead, row);
+    const float nb2 = (metric == 2u || !live) ? 1.0f : norm2[row];
+    const bool forced = !(nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY));
+    float sc = metric == 0u ? (nb2 > 0.0f ? __builtin_amdgcn_rsqf(nb2) : 0.0f) : (metric == 1u ? 2.0f : 1.0f);
+    float sh = metric == 1u ? -nb2 : 0.0f;
+    sc = forced ? 0.0f : sc;
+    sh = forced ? INFINITY : sh;
+    sc = live ? sc : 0.0f;
+    sh = live ? sh : -INFINITY;
+    return make_float2(sc, sh);
+}
+
 // Largest value over the 64 lanes of a wave (every lane must call it).
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll

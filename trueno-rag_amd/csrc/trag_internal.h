@@ -189,8 +189,11 @@ hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanA
                                uint32_t* d_out_rows, float* d_out_scores, uint32_t* d_out_n,
                                uint32_t* d_status, hipStream_t st);
 // pieces of the batched path reused by the bf16 prefilter
-hipError_t launch_batch_prep(const float* d_Q, uint32_t n_queries, uint32_t dim, SearchCtl* ctls,
-                             uint32_t need, uint32_t k, const float* d_vmax_sq, hipStream_t st);
+// one launch before the prefilter's first pass: norms and control blocks of the queries, the queries as
+// bf16 (zero rows up to `padded`), and with_rowc the per-row (scale, shift) table
+hipError_t launch_bf16_prep(const float* d_Q, uint32_t n_queries, uint32_t padded, const ScanArgs& a,
+                            const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
+                            const float* d_vmax_sq, bool with_rowc, hipStream_t st);
 void launch_tau_select(const uint32_t* tmax, size_t tmax_stride, uint32_t n_tiles64, SearchCtl* ctls,
                        uint32_t n_queries, hipStream_t st);
 // bf16 prefilter (trag_bf16.hip) and its exact finish (trag_kernels.hip)
@@ -211,7 +214,7 @@ bool qs_supports(uint32_t dim, uint32_t metric);
 uint32_t qs_group_queries(uint32_t dim);
 uint32_t qs_max_batch(uint32_t dim);
 uint32_t qs_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim);
-hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+hipError_t launch_qs_scan(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
                           const float* d_norm2, const Bf16Scratch& s, uint32_t need, hipStream_t st);
 // bf16 mirror of the corpus (trag_mirror.hip) and the stages after its scan (trag_kernels.hip)
 hipError_t launch_to_bf16(const float* d_src, uint64_t n_floats, uint16_t* d_dst, hipStream_t st);

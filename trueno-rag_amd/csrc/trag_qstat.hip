@@ -628,29 +628,6 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     }
 }
 
-// Per corpus row, once per batch: the row-dependent part of a score is v = fma(dot, scale, shift) --
-// cosine dot / ||v||, dot product dot, Euclidean 2 dot - ||v||^2. Rows that take no part (removed,
-// past the end): scale 0, shift -inf. Rows whose norm is outside the bound's range must always be
-// candidates: scale 0, shift +inf (the sample pass leaves them out). The reciprocal square root is
-// the hardware's (1 ulp): v only has to be within the bound's 1 % slack of its value. Written for
-// every row up to the next multiple of 64 (the GEMM's tiles read that far).
-__global__ void __launch_bounds__(256)
-qs_rowc_kernel(const float* __restrict__ norm2, const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t n_pad,
-               uint32_t metric, float2* __restrict__ rowc) {
-    for (uint32_t row = blockIdx.x * 256u + threadIdx.x; row < n_pad; row += gridDim.x * 256u) {
-        const bool live = row < n_rows && !row_is_dead(dead, row);
-        const float nb2 = (metric == 2u || !live) ? 1.0f : norm2[row];
-        const bool forced = !(nb2 == 0.0f || (nb2 >= 0x1p-100f && nb2 < INFINITY));
-        float sc = metric == 0u ? (nb2 > 0.0f ? __builtin_amdgcn_rsqf(nb2) : 0.0f) : (metric == 1u ? 2.0f : 1.0f);
-        float sh = metric == 1u ? -nb2 : 0.0f;
-        sc = forced ? 0.0f : sc;
-        sh = forced ? INFINITY : sh;
-        sc = live ? sc : 0.0f;
-        sh = live ? sh : -INFINITY;
-        rowc[row] = make_float2(sc, sh);
-    }
-}
-
 // Per query, after the full pass: the candidate list holds every row whose approximate score v
 // reaches the sample's threshold, with v. A = the need-th largest finite v of the list: `need`
 // rows reach A approximately, so the exact need-th best is >= A - eps and every row of the exact
@@ -828,8 +805,6 @@ uint32_t qs_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
 }
 
 // declared in trag_bf16.hip
-void launch_queries_to_bf16(const float* d_Q, uint32_t n_queries, uint32_t padded, uint32_t dim, uint16_t* qb,
-                            hipStream_t st);
 void launch_shift_threshold(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t padded, uint32_t dim,
                             hipStream_t st);
 
@@ -843,17 +818,11 @@ void launch_qs_prune(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, 
 }
 
 // The whole prefilter for up to qs_max_batch(dim) queries: sample pass, thresholds, full pass, prune.
-// The caller has run launch_batch_prep (norms, control blocks).
-hipError_t launch_qs_scan(const float* d_Q, uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
+// The caller has run launch_bf16_prep (norms, control blocks, bf16 queries, per-row constants).
+hipError_t launch_qs_scan(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
                           const float* d_norm2, const Bf16Scratch& s, uint32_t need, hipStream_t st) {
     const uint32_t QW = qs_group_queries(a.dim);
     const uint32_t padded = (n_queries + QW - 1) / QW * QW;
-    launch_queries_to_bf16(d_Q, n_queries, padded, a.dim, s.qb, st);
-    {
-        const uint32_t n_pad = (a.n_rows + 63u) / 64u * 64u;
-        hipLaunchKernelGGL(qs_rowc_kernel, dim3(std::min<uint32_t>((n_pad + 255u) / 256u, 2048u)), dim3(256), 0, st,
-                           d_norm2, a.dead, a.n_rows, n_pad, a.metric, reinterpret_cast<float2*>(s.rowc));
-    }
     const uint32_t step = qs_sample_step(a.n_rows, need, a.dim);
     const uint32_t RT = qs_tile_rows(a.dim);
     if (d_mirror) qs_launch<0, true>(n_queries, a, d_mirror, d_norm2, s, step, need, st);
