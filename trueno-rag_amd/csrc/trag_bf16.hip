@@ -514,6 +514,9 @@ uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
 static int bf16_variant(uint32_t n_queries) {
     return n_queries <= 32 ? 0 : (n_queries <= 64 ? 1 : (n_queries <= 128 ? 2 : 3));
 }
+// (The sample pass runs at the full pass's rate per byte, not at a latency floor: with 128 x 128 tiles --
+// four times as many workgroups, each a quarter of the work -- the sample of 1 M x 768 for 256 queries,
+// every 16th tile, took 67 us instead of 50 from f32 rows and 48 instead of 36 from the mirror.)
 static uint32_t bf16_tile_rows(uint32_t n_queries) {
     const int v = bf16_variant(n_queries);
     return v == 2 ? 128 : 256;
