@@ -754,34 +754,61 @@ def test_concurrent_searches_on_one_handle(trag, oracle):
     assert not errors, errors[0]
 
 
+def device_searches_one_by_one(store, Q, k, sync=True):
+    """Each query through trag_store_search_device on torch's current stream; statuses and results."""
+    import torch
+    nq = len(Q)
+    dq = torch.from_numpy(Q).cuda()
+    o_rows = torch.zeros((nq, k), dtype=torch.int32, device="cuda")
+    o_scores = torch.zeros((nq, k), dtype=torch.float32, device="cuda")
+    o_n = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    o_st = torch.full((nq,), 9, dtype=torch.int32, device="cuda")
+    sp = torch.cuda.current_stream().cuda_stream
+    for b in range(nq):
+        store.search_device(dq[b].data_ptr(), 1, k, o_rows[b].data_ptr(), o_scores[b].data_ptr(),
+                            o_n[b].data_ptr(), o_st[b].data_ptr(), sp)
+        if sync:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return o_st.tolist(), o_rows.cpu().numpy().astype(np.uint32), o_scores.cpu().numpy()
+
+
 def test_device_entry_learns_the_multi_level_select(trag, oracle):
     """Callers of trag_store_search_device never hand a status back. On a corpus whose scores
-    crowd one coarse bin (Euclidean distances between unit vectors are all close to sqrt 2) the
+    crowd one coarse bin (rows packed around one direction: every cosine lies in a narrow band) the
     first queries report status 3; the handle must notice by itself (pinned host word bumped by
     the select kernel) and serve later queries with the multi-level select."""
-    import torch
-    n, d, k = 100_000, 384, 10
+    n, d, k = 60_000, 384, 10
     rng = np.random.default_rng(2718)
+    centre = unit_rows(rng, 1, d)[0]
+    corpus = np.ascontiguousarray(centre[None, :] + 0.02 * rng.standard_normal((n, d)), dtype=np.float32)
+    store = make_store(trag, d, 0)
+    store.insert_rows(corpus)
+    Q = np.ascontiguousarray(centre[None, :] + 0.02 * rng.standard_normal((24, d)), dtype=np.float32)
+    st, rows, scores = device_searches_one_by_one(store, Q, k)
+    assert st[0] == 3, st                 # crowded coarse bin
+    assert st[-8:] == [0] * 8, st         # learned within a few queries
+    for b in range(16, 24):
+        er, es = oracle.search(corpus, Q[b], k, 0)
+        assert_same_ranking(rows[b], scores[b], er, es, f"dev clustered {b}")
+
+
+def test_device_entry_on_a_short_euclidean_store_needs_no_learning(trag, oracle):
+    """Euclidean distances between unit vectors without near neighbours are all close to sqrt 2: one
+    coarse bin holds nearly every row. A store too short for sparse key stores starts on the
+    multi-level select, so even queries enqueued far ahead of any synchronisation finish (status 0)
+    with the oracle's rows and score bits."""
+    n, d, k = 100_000, 384, 10
+    rng = np.random.default_rng(2719)
     corpus = unit_rows(rng, n, d)
     store = make_store(trag, d, 1)
     store.insert_rows(corpus)
     Q = unit_rows(rng, 24, d)
-    dq = torch.from_numpy(Q).cuda()
-    o_rows = torch.zeros((24, k), dtype=torch.int32, device="cuda")
-    o_scores = torch.zeros((24, k), dtype=torch.float32, device="cuda")
-    o_n = torch.zeros(24, dtype=torch.int32, device="cuda")
-    o_st = torch.full((24,), 9, dtype=torch.int32, device="cuda")
-    sp = torch.cuda.current_stream().cuda_stream
-    for b in range(24):
-        store.search_device(dq[b].data_ptr(), 1, k, o_rows[b].data_ptr(), o_scores[b].data_ptr(),
-                            o_n[b].data_ptr(), o_st[b].data_ptr(), sp)
-        torch.cuda.synchronize()
-    st = o_st.tolist()
-    assert st[0] == 3, st                 # crowded coarse bin
-    assert st[-8:] == [0] * 8, st         # learned within a few queries
-    for b in range(16, 24):
+    st, rows, scores = device_searches_one_by_one(store, Q, k, sync=False)
+    assert st == [0] * 24, st
+    for b in (0, 1, 7, 23):
         er, es = oracle.search(corpus, Q[b], k, 1)
-        assert_same_ranking(o_rows[b].cpu().numpy().astype(np.uint32), o_scores[b].cpu().numpy(), er, es, f"dev eu {b}")
+        assert_same_ranking(rows[b], scores[b], er, es, f"dev eu {b}")
 
 
 def test_striped_store_on_one_gpu(trag, oracle):

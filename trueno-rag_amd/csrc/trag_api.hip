@@ -508,6 +508,17 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         const uint32_t ev = *static_cast<volatile uint32_t*>(s->h_events);
         if (ev >= 4 && (uint64_t)ev * 2 >= s->one_wg_queries) s->full_select = true;
     }
+    // Euclidean stores too short for sparse key stores go straight to the multi-level select. Distances
+    // between normalised embeddings without near neighbours lie within a few per cent of one another:
+    // nearly every row shares the coarse bin (sign, exponent, two mantissa bits) of the k-th best, the
+    // one-workgroup select gives up, and a caller of the device entry points, who enqueues far ahead,
+    // would see that status on every query enqueued before the handle had learned it. The multi-level
+    // form costs 8 us a query more (10 k rows: 41 against 33 us; 1 M: 0.256 against 0.253 ms); on
+    // longer scans it would also cost the sparse key stores (10 M x 384: 2.33 against 2.23 ms), so
+    // those still start with the one-workgroup form and learn.
+    if (!s->full_select && s->cfg.metric == TRAG_EUCLIDEAN &&
+        !sparse_scan_pays((uint32_t)((s->n_rows + 63) / 64), 1024u) && !getenv("TRAG_EUCLID_ONE_WG"))
+        s->full_select = true;
     s->scratch.epoch = 0;  // sparse key stores: only the single-query scans below switch them on
     if (k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP) {
         // More results than the one-workgroup sort holds: exact scan, then a
