@@ -49,7 +49,7 @@ def parse():
                     help="hybrid step: dense top-50 + BM25 top-50 (synthetic documents) -> RRF(60) -> top-k on the host")
     ap.add_argument("--host", action="store_true",
                     help="time the host-pointer entry (trag_store_search: query from host memory, results to host "
-                         "memory, synchronous) instead of the device-resident one; the shape of BASELINE config 1")
+                         "memory, synchronous) instead of the device-resident one; the shape of the smallest benchmark configuration (10 000 x 384)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter pass that measures the scan kernel's HBM traffic")
@@ -443,7 +443,7 @@ def rccl_version_or_zero():
 
 
 def exchange_batch_leg(args, store, group, ex, side, rank, world, row0, d, k, seed, sptr, stream, fence, dist):
-    """Second leg of a sharded run: 1000 queries per step (BASELINE config 4's batch) through the
+    """Second leg of a sharded run: 1000 queries per step (the batch of the 8-GPU benchmark configuration) through the
     same local search -> all-gather -> merge step. Reported beside the headline leg."""
     BX = 1000
     steps, warm = max(2, min(args.steps, 10)), 1

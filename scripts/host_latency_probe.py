@@ -1,5 +1,5 @@
 """GPU-box probe: latency of the host-pointer entry point (trag_store_search) on small stores --
-BASELINE config 1 (10 000 x 384, one query, top 10) and two larger sizes."""
+the smallest benchmark configuration (10 000 x 384, one query, top 10) and two larger sizes."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -3,7 +3,7 @@
 * two ranks, started by bench.py itself from a plain `python bench.py --gpus 2` (no launcher):
   both share cuda:0, so the exchange is the Python rehearsal over gloo (RCCL refuses two ranks on
   one device); the numbers mean nothing, the parity fields do. The run carries the second leg with
-  1000 queries per step (BASELINE config 4's batch) through the same exchange.
+  1000 queries per step (the batch of the 8-GPU benchmark configuration) through the same exchange.
 * one rank with the exchange forced on: the step is ONE trag_shard_search_device call and the
   all-gather is RCCL inside the library."""
 import json

@@ -545,7 +545,7 @@ def test_large_k_returns_every_row_sorted(trag, oracle, metric):
 
 
 def test_config1_mock_embedder_corpus(trag, oracle):
-    """BASELINE config 1 with the reference's own generator: MockEmbedder(384) vectors of
+    """The smallest benchmark configuration (10 000 x 384, top 10) with the reference's own generator: MockEmbedder(384) vectors of
     10k texts, one query, top-10 (benches/retrieval.rs shape, src/embed.rs:124-155 inputs)."""
     e = trag.MockEmbedder.new(384)
     n = 10_000
