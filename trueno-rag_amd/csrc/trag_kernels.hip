@@ -660,7 +660,8 @@ rescore_kernel(const float* __restrict__ corpus, const float* __restrict__ Q, ui
                const SearchCtl* __restrict__ ctls, const uint32_t* __restrict__ cand,
                uint32_t* __restrict__ out_keys) {
     constexpr int CW = 32, STRIDE = CW + 4;
-    __shared__ __attribute__((aligned(16))) float tiles[4][64 * STRIDE];
+    // per wave: 64 rows of a chunk, and the query's 32 components of the same chunk behind them
+    __shared__ __attribute__((aligned(16))) float tiles[4][65 * STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t y = blockIdx.x;
     const SearchCtl* ctl = ctls + y;
@@ -679,33 +680,76 @@ rescore_kernel(const float* __restrict__ corpus, const float* __restrict__ Q, ui
         rptr[i] = corpus + (size_t)min(cq[ci], n_rows - 1u) * d;
     }
     const uint32_t d4 = d >> 2, n_chunks = (d + CW - 1) / CW;
-    v4f pre[8];
-    auto issue = [&](uint32_t c) {
+    // PF chunks of loads in flight: the rows are scattered over the corpus and a wave has nothing else
+    // to do while it waits. The query's components travel with them (every lane group of 8 loads the
+    // chunk's 128 bytes; they are read back from LDS as broadcasts): fetched through the scalar cache
+    // instead, chunk by chunk, they cost a round trip to L2 per 32 columns that nothing overlapped
+    // (1000 queries x ~25 rows of 384 floats: 25 us; 256 x ~40 rows of 768: 31 us).
+#ifndef RESCORE_PF
+#define RESCORE_PF 2
+#endif
+    constexpr int PF = RESCORE_PF;
+    v4f pre[PF][8], pre_q[PF];
+    auto issue = [&](uint32_t c, v4f (&dst)[8], v4f& dst_q) {
         const uint32_t col4 = min(c * 8u + (uint32_t)lcol, d4 - 1u);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pre[i] = reinterpret_cast<const v4f*>(rptr[i])[col4];
+        for (int i = 0; i < 8; ++i) dst[i] = reinterpret_cast<const v4f*>(rptr[i])[col4];
+        dst_q = reinterpret_cast<const v4f*>(q)[col4];
     };
-    issue(0);
+#pragma unroll
+    for (int p = 0; p < PF; ++p) issue((uint32_t)p, pre[p], pre_q[p]);
     float acc0 = 0.0f, acc1 = 0.0f;
-    for (uint32_t c = 0; c < n_chunks; ++c) {
+    float* qrow = tile + 64 * STRIDE;
+    auto stage = [&](const v4f (&src)[8], const v4f& src_q) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            *reinterpret_cast<v4f*>(&tile[(i * 8 + lrow) * STRIDE + lcol * 4]) = pre[i];
+            *reinterpret_cast<v4f*>(&tile[(i * 8 + lrow) * STRIDE + lcol * 4]) = src[i];
+        if (lrow == 0) *reinterpret_cast<v4f*>(&qrow[lcol * 4]) = src_q;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (c + 1 < n_chunks) issue(c + 1);
-        const float* __restrict__ qc = q + c * CW;
-        const float* myrow = tile + lane * STRIDE;
-        const uint32_t len = min((uint32_t)CW, d - c * CW);
-        for (uint32_t j = 0; j < len / 4; ++j) {
-            const v4f x = *reinterpret_cast<const v4f*>(myrow + j * 4);
-            accum<METRIC>(qc[j * 4 + 0], x.x, acc0, acc1);
-            accum<METRIC>(qc[j * 4 + 1], x.y, acc0, acc1);
-            accum<METRIC>(qc[j * 4 + 2], x.z, acc0, acc1);
-            accum<METRIC>(qc[j * 4 + 3], x.w, acc0, acc1);
+    };
+    const float* myrow = tile + lane * STRIDE;
+    // Groups of PF whole chunks: one chain of basic blocks without a branch, every slot staged, refilled
+    // (past the end: a clamped, harmless address) and summed in turn, so that the loads in flight are
+    // the same at every step and the compiler waits for a slot with a counted vmcnt.
+    const uint32_t n_whole = d / CW;
+    uint32_t c0 = 0;
+    for (; c0 + PF <= n_whole; c0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            stage(pre[p], pre_q[p]);
+            issue(c0 + (uint32_t)p + PF, pre[p], pre_q[p]);
+#pragma unroll
+            for (int j = 0; j < CW / 4; ++j) {
+                const v4f x = *reinterpret_cast<const v4f*>(myrow + j * 4);
+                const v4f qv = *reinterpret_cast<const v4f*>(qrow + j * 4);
+                accum<METRIC>(qv.x, x.x, acc0, acc1);
+                accum<METRIC>(qv.y, x.y, acc0, acc1);
+                accum<METRIC>(qv.z, x.z, acc0, acc1);
+                accum<METRIC>(qv.w, x.w, acc0, acc1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    }
+    // what is left: fewer than PF whole chunks and a last narrow one, already on their way
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const uint32_t c = c0 + (uint32_t)p;
+        if (c < n_chunks) {
+            stage(pre[p], pre_q[p]);
+            const uint32_t len = min((uint32_t)CW, d - c * CW);
+            for (uint32_t j = 0; j < len / 4; ++j) {
+                const v4f x = *reinterpret_cast<const v4f*>(myrow + j * 4);
+                const v4f qv = *reinterpret_cast<const v4f*>(qrow + j * 4);
+                accum<METRIC>(qv.x, x.x, acc0, acc1);
+                accum<METRIC>(qv.y, x.y, acc0, acc1);
+                accum<METRIC>(qv.z, x.z, acc0, acc1);
+                accum<METRIC>(qv.w, x.w, acc0, acc1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     const uint32_t i = base + (uint32_t)lane;
     if (i < C) out_keys[(size_t)y * CAND_CAP + i] = score_key(finish_score<METRIC>(acc0, acc1, ctl->na));
@@ -785,9 +829,57 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
     uint32_t C = use_count ? ctl->cand_count : ctl->expect;
     const bool overflow = C > CAND_CAP;
     if (C > CAND_CAP) C = CAND_CAP;
+    const float na = ctl->na;
+    if (C <= 64u) {
+        // the usual case behind the bf16 prefilter's prune stage (some tens of rows): one wave sorts
+        // them in registers, without a barrier; the other waves leave at once
+        if (tid >= 64) return;
+        const int lane = tid;
+        unsigned long long v = 0ull;
+        if ((uint32_t)lane < C) {
+            const uint32_t row = cand[lane];
+            uint32_t skey;
+            if (RESCORE)
+                skey = pre_keys ? pre_keys[lane]
+                                : score_key(exact_score_row<METRIC>(corpus + (size_t)row * d, q, d, na));
+            else
+                skey = keys[row];
+            v = rank_key(skey, row);
+        }
+#pragma unroll
+        for (int size = 2; size <= 64; size <<= 1) {
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, stride);
+                const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), stride);
+                const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+                const bool desc = (lane & size) == 0;
+                const bool lower = (lane & stride) == 0;
+                const unsigned long long mx = v > o ? v : o, mn = v > o ? o : v;
+                v = (lower == desc) ? mx : mn;
+            }
+        }
+        const uint32_t k = ctl->k;
+        const uint32_t n_out = k < C ? k : C;
+        const float sc = key_score((uint32_t)(v >> 32));
+        if ((uint32_t)lane < n_out) {
+            out_rows[lane] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
+            out_scores[lane] = (METRIC == 1 && sc == 0.0f) ? -0.0f : sc;  // -(sqrt(0)) in the reference
+        }
+        const float ek = __shfl(sc, n_out > 0 ? (int)n_out - 1 : 0);
+        if (lane == 0) {
+            *out_n = n_out;
+            uint32_t status = ST_OK;
+            if (RESCORE && C < live && n_out > 0)
+                status = certify<METRIC>(ctl, d, na, ctl->t_key, ek, use_count);
+            ctl->levels = ctl->resolved ? ctl->resolved : 3;
+            ctl->status = status;
+            if (out_status) *out_status = status;
+        }
+        return;
+    }
     uint32_t P = 64;
     while (P < C) P <<= 1;
-    const float na = ctl->na;
     for (uint32_t i = tid; i < P; i += 1024u) {
         unsigned long long v = 0ull;
         if (i < C) {

@@ -671,10 +671,73 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     if (C > CAND_CAP || C <= need) return;
     uint32_t* cq = cand + (size_t)y * CAND_CAP;
     const uint32_t* vq = cvals + (size_t)y * CAND_CAP;
-    uint32_t P = 64;
-    while (P < C) P <<= 1;
     if (tid == 0) { n_inf_sh = 0; keep_sh = 0; }
     __syncthreads();
+    if (C <= 2u * PRUNE_THREADS) {
+        // Lists of a few hundred entries (the usual case) are ranked by counting: every thread
+        // counts, for its one or two entries, the entries that sort before them -- two barriers where
+        // a sorting network for 256 entries takes 36 (the stage's time: 29 us for 1000 queries
+        // with lists of ~150). The survivors land where the sort would have put them.
+        unsigned long long mine[2];
+        uint32_t n_inf = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)e * PRUNE_THREADS;
+            mine[e] = 0ull;
+            if (i < C) {
+                const float v = __uint_as_float(vq[i]);
+                rows[i] = cq[i];
+                const uint32_t key = (v != v || v == INFINITY) ? 0xFFFFFFFFu : score_key(v);
+                n_inf += key == 0xFFFFFFFFu;
+                mine[e] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+                sk[i] = mine[e];
+            }
+        }
+        if (n_inf) atomicAdd(&n_inf_sh, n_inf);
+        __syncthreads();
+        const uint32_t F = n_inf_sh;
+        if (F + need > C) return;   // fewer than `need` rows with a usable score: keep the whole list
+        uint32_t above[2] = {0u, 0u};
+        for (uint32_t j = 0; j < C; ++j) {
+            const unsigned long long o = sk[j];
+            above[0] += o > mine[0];
+            above[1] += o > mine[1];
+        }
+        // (entry i has rank above[e] in descending order; the padding entries of a thread, 0, rank last)
+        __shared__ uint32_t a_key_sh;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if ((uint32_t)tid + (uint32_t)e * PRUNE_THREADS < C && above[e] == F + need - 1u) a_key_sh = (uint32_t)(mine[e] >> 32);
+        __syncthreads();
+        const float A = key_score(a_key_sh);
+        const float vmax = sqrtf(ctl->vmax_sq);
+        const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
+        float t, tv;
+        if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
+        else if (METRIC == 1) { t = (A - na_sq) - 2.02f * eps; tv = t + na_sq; }
+        else { t = A - 2.02f * eps; tv = t; }
+        if (!(t == t) || !(tv == tv) || !(tv > tv_cur)) return;   // nothing gained (or out of range): keep the list
+        const uint32_t tkey = score_key(tv);
+        uint32_t kept = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)e * PRUNE_THREADS;
+            if (i < C && (uint32_t)(mine[e] >> 32) >= tkey) {
+                cq[above[e]] = rows[i];
+                ++kept;
+            }
+        }
+        if (kept) atomicAdd(&keep_sh, kept);
+        __syncthreads();
+        if (tid == 0) {
+            ctl->cand_count = keep_sh;
+            ctl->t_key = score_key(t);
+            thr[y] = tv;
+        }
+        return;
+    }
+    uint32_t P = 64;
+    while (P < C) P <<= 1;
     uint32_t n_inf = 0;
     for (uint32_t i = tid; i < P; i += (uint32_t)PRUNE_THREADS) {
         unsigned long long e = 0ull;
