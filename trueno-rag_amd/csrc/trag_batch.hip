@@ -423,12 +423,6 @@ hipError_t launch_bf16_prep(const float* d_Q, uint32_t n_queries, uint32_t padde
     return hipGetLastError();
 }
 
-void launch_tau_select(const uint32_t* tmax, size_t tmax_stride, uint32_t n_tiles64, SearchCtl* ctls,
-                       uint32_t n_queries, hipStream_t st) {
-    hipLaunchKernelGGL(tau_select_kernel, dim3(n_queries), dim3(1024), 0, st, tmax, tmax_stride, n_tiles64,
-                       ctls);
-}
-
 bool batch_supports(uint32_t dim, uint32_t metric) {
     return (dim % BT_KMIN) == 0 && metric <= TRAG_DOT_PRODUCT;
 }

@@ -38,43 +38,143 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BF_K = 64;   // f32 columns staged per step (= 4 MFMA k-steps of 16)
 constexpr int BF_LD = 36;  // dwords per LDS row: 64 bf16 + 4 dwords of padding (conflict-free b128 reads)
 
-// After tau_select on the sample's tile maxima, which are keys of the row-dependent part
-// v of the score (cosine v = dot * inv_nb = score * ||q||; dot product v = score;
-// Euclidean v = 2 dot - ||v||^2 = -(squared distance) + ||q||^2): lower each query's
-// threshold by 2 eps (see the header), publish it in v-space for the full pass, and
-// keep it in score space (t_key) for the final check. A query whose scale is outside
-// the bound's range gets the threshold -inf: its list overflows and the host repeats it
-// with the exact scan.
-template <int METRIC>
-__global__ void shift_threshold_kernel(SearchCtl* __restrict__ ctls, uint32_t n_queries, uint32_t d,
-                                       float* __restrict__ thr, uint32_t padded, uint32_t* __restrict__ dyn_lvl,
-                                       float* __restrict__ dyn_lad, uint32_t* __restrict__ dyn_cnt) {
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= padded) return;
-    // the ladder of the thresholds that tighten during the full pass (trag_device.h): level 0 is
-    // the threshold found here, a step is a quarter of 2.02 eps in v-space; no ladder (step 0)
-    // for a query without a finite threshold, +inf for the padding behind the batch
-    float t = -INFINITY, v = q < n_queries ? -INFINITY : INFINITY, step = 0.0f;
-    if (q < n_queries) {
-        SearchCtl* ctl = ctls + q;
-        const uint32_t tk = ctl->t_key;
-        const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
-        const bool in_range = na * vmax < 1e30f && (METRIC != 0 || na > 0.0f);  // false for NaN too
-        if (tk >= 0x007FFFFFu && in_range) {
-            const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
-            const float tv = key_score(tk);
-            if (METRIC == 0) { t = tv / na - 2.02f * eps; v = t * na; step = 2.02f * eps * na; }
-            else if (METRIC == 1) { t = (tv - ctl->na_sq) - 2.02f * eps; v = t + ctl->na_sq; step = 2.02f * eps; }
-            else { t = tv - 2.02f * eps; v = t; step = 2.02f * eps; }
-            step *= 1.0f / (float)DYN_SUB;
-        }
-        if (!(t == t) || !(v == v)) { t = -INFINITY; v = -INFINITY; }
-        if (!(v > -INFINITY && v < INFINITY && step > 0.0f && step < INFINITY)) step = 0.0f;
-        ctl->t_key = t > -INFINITY ? score_key(t) : 1u;
-        thr[q] = v;
+// find_bin over a 2048-bin histogram in LDS, called by all 256 threads of the workgroup: the highest
+// bin whose suffix count reaches `need`, and the count strictly above it. sh: 6 words.
+constexpr int TAU_THREADS = 256;
+__device__ __forceinline__ void find_bin_256(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
+                                             uint32_t* sh) {
+    static_assert(HIST_BINS == 8 * TAU_THREADS, "eight bins per thread");
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int top = (int)HIST_BINS - 1 - 8 * t;  // thread t owns bins top, top - 1, ..., top - 7
+    uint32_t h[8], sum = 0;
 #pragma unroll
-        for (uint32_t j = 0; j < DYN_LEVELS; ++j) dyn_cnt[(size_t)q * DYN_LEVELS + j] = 0u;
+    for (int i = 0; i < 8; ++i) {
+        h[i] = hist[top - i];
+        sum += h[i];
     }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) sh[w] = incl;
+    if (t == 0) { sh[4] = 0; sh[5] = 0; }
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) base += sh[i];
+        total += sh[i];
+    }
+    incl += base;
+    if (need > total) need = total;
+    uint32_t run = incl - sum;
+    if (need > 0 && run < need && need <= incl) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (run < need && run + h[i] >= need) { sh[4] = (uint32_t)(top - i); sh[5] = run; }
+            run += h[i];
+        }
+    }
+    __syncthreads();
+    bin = sh[4];
+    above = sh[5];
+    __syncthreads();
+}
+
+// Between the sample pass and the full pass, one workgroup per query.
+// First the query's threshold in key space: the need-th largest of the sample's tile maxima (at
+// least `need` sampled rows reach it), by three radix levels (11 + 11 + 10 bits) over the maxima,
+// which a thread keeps in registers (up to 16 each; more are re-read per level). The maxima are keys
+// of the row-dependent part v of the score (cosine v = dot * inv_nb = score * ||q||; dot product
+// v = score; Euclidean v = 2 dot - ||v||^2 = -(squared distance) + ||q||^2).
+// Then the threshold is lowered by 2 eps (see the header), published in v-space for the full pass
+// and kept in score space (t_key) for the final check, and the ladder of the thresholds that tighten
+// during the full pass (trag_device.h) is set up: level 0 is the threshold found here, a step is
+// 2.02 eps / DYN_SUB in v-space; no ladder (step 0) for a query without a finite threshold. A
+// query whose scale is outside the bound's range gets the threshold -inf: its list overflows and
+// the host repeats it with the exact scan. Workgroups behind the batch write the padding of the
+// ladder arrays (+inf: the passes read whole query groups).
+// (256 threads, so that a CU holds eight queries at a time: the stage is three dependent rounds of
+// barriers per query, not work. As two launches -- 1024 threads re-reading the maxima per level, then a
+// kernel for the ladder -- it took 17 + 5.5 us for 1000 queries.)
+template <int METRIC>
+__global__ void __launch_bounds__(TAU_THREADS)
+tau_shift_kernel(const uint32_t* __restrict__ tmax, size_t tmax_stride, uint32_t n_tiles,
+                 SearchCtl* __restrict__ ctls, uint32_t n_queries, uint32_t padded, uint32_t d,
+                 float* __restrict__ thr, uint32_t* __restrict__ dyn_lvl, float* __restrict__ dyn_lad,
+                 uint32_t* __restrict__ dyn_cnt) {
+    __shared__ uint32_t lhist[HIST_BINS];
+    __shared__ uint32_t sh[6];
+    const int tid = threadIdx.x;
+    const uint32_t q = blockIdx.x;
+    if (q >= n_queries) {
+        const uint32_t i = n_queries + (q - n_queries) * (uint32_t)TAU_THREADS + (uint32_t)tid;
+        if (i < padded) {
+            dyn_lvl[i] = 0u;
+            dyn_lad[2 * i] = INFINITY;
+            dyn_lad[2 * i + 1] = 0.0f;
+        }
+        return;
+    }
+    const uint32_t* tm = tmax + (size_t)q * tmax_stride;
+    SearchCtl* ctl = ctls + q;
+    uint32_t need = ctl->need;
+    for (uint32_t j = (uint32_t)tid; j < DYN_LEVELS; j += (uint32_t)TAU_THREADS) dyn_cnt[(size_t)q * DYN_LEVELS + j] = 0u;
+    constexpr int KEEP = 16;
+    uint32_t mine[KEEP];
+#pragma unroll
+    for (int j = 0; j < KEEP; ++j) {
+        const uint32_t i = (uint32_t)j * TAU_THREADS + (uint32_t)tid;
+        mine[j] = i < n_tiles ? tm[i] : 0u;
+    }
+    uint32_t prefix = 0, prefix_bits = 0;
+    if (need <= n_tiles) {   // (fewer tiles than wanted rows: every live row, key 1)
+        const int shifts[3] = {21, 10, 0};
+        const uint32_t widths[3] = {11, 11, 10};
+#pragma unroll
+        for (int level = 0; level < 3; ++level) {
+            for (int i = tid; i < (int)HIST_BINS; i += TAU_THREADS) lhist[i] = 0u;
+            __syncthreads();
+            const uint32_t mshift = 32u - prefix_bits;
+            const uint32_t shift = (uint32_t)shifts[level], mask = (1u << widths[level]) - 1u;
+#pragma unroll
+            for (int j = 0; j < KEEP; ++j) {
+                const uint32_t i = (uint32_t)j * TAU_THREADS + (uint32_t)tid;
+                const bool match = prefix_bits == 0 || (mine[j] >> mshift) == prefix;
+                if (i < n_tiles && match) atomicAdd(&lhist[(mine[j] >> shift) & mask], 1u);
+            }
+            for (uint32_t i = (uint32_t)(KEEP * TAU_THREADS) + (uint32_t)tid; i < n_tiles; i += (uint32_t)TAU_THREADS) {
+                const uint32_t v = tm[i];
+                const bool match = prefix_bits == 0 || (v >> mshift) == prefix;
+                if (match) atomicAdd(&lhist[(v >> shift) & mask], 1u);
+            }
+            __syncthreads();
+            uint32_t bin, above;
+            find_bin_256(lhist, need, bin, above, sh);
+            need -= above;
+            prefix = (prefix << widths[level]) | bin;
+            prefix_bits += widths[level];
+        }
+    }
+    if (tid != 0) return;
+    const uint32_t tk = prefix > 1u ? prefix : 1u;
+    float t = -INFINITY, v = -INFINITY, step = 0.0f;
+    const float na = ctl->na, vmax = sqrtf(ctl->vmax_sq);
+    const bool in_range = na * vmax < 1e30f && (METRIC != 0 || na > 0.0f);  // false for NaN too
+    if (tk >= 0x007FFFFFu && in_range) {
+        const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
+        const float tv = key_score(tk);
+        if (METRIC == 0) { t = tv / na - 2.02f * eps; v = t * na; step = 2.02f * eps * na; }
+        else if (METRIC == 1) { t = (tv - ctl->na_sq) - 2.02f * eps; v = t + ctl->na_sq; step = 2.02f * eps; }
+        else { t = tv - 2.02f * eps; v = t; step = 2.02f * eps; }
+        step *= 1.0f / (float)DYN_SUB;
+    }
+    if (!(t == t) || !(v == v)) { t = -INFINITY; v = -INFINITY; }
+    if (!(v > -INFINITY && v < INFINITY && step > 0.0f && step < INFINITY)) step = 0.0f;
+    ctl->t_key = t > -INFINITY ? score_key(t) : 1u;
+    thr[q] = v;
     dyn_lvl[q] = 0u;
     dyn_lad[2 * q] = v;
     dyn_lad[2 * q + 1] = step;
@@ -556,6 +656,9 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
 #undef TRAG_LAUNCH_BF16
 }
 
+void launch_tau_shift(uint32_t metric, const Bf16Scratch& s, uint32_t n_maxima, uint32_t n_queries, uint32_t padded,
+                      uint32_t dim, hipStream_t st);
+
 // The caller has run launch_bf16_prep (norms, control blocks, bf16 queries).
 template <int METRIC, bool MIR>
 static void bf16_scan_metric(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
@@ -568,24 +671,23 @@ static void bf16_scan_metric(uint32_t n_queries, const ScanArgs& a, const uint16
     const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
     const uint32_t pass_tiles = (n_row_tiles + step - 1) / step;
     const uint32_t n_tile64 = pass_tiles * (BN / 32);  // maxima per 32 rows; every sampled workgroup writes all of its own
-    launch_tau_select(s.tmax, s.tmax_stride, n_tile64, s.ctls, n_queries, st);
-    hipLaunchKernelGGL(shift_threshold_kernel<METRIC>, dim3(padded / 256), dim3(256), 0, st, s.ctls,
-                       n_queries, a.dim, s.thr, padded, s.dyn_lvl, s.dyn_lad, s.dyn_cnt);
+    launch_tau_shift(METRIC, s, n_tile64, n_queries, padded, a.dim, st);
     launch_gemm_bf16<METRIC, 1, MIR>(n_queries, a, d_mirror, d_norm2, s, 1, need, st);
     // the lists hold every row above the sample's threshold, with its approximate value: keep the
     // rows within 2 eps of the list's need-th largest value (trag_qstat.hip)
     launch_qs_prune(METRIC, s, n_queries, a.dim, st);
 }
 
-void launch_shift_threshold(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t padded, uint32_t dim,
-                            hipStream_t st) {
-    const dim3 grid((padded + 255) / 256), block(256);
-#define TRAG_SHIFT(M) hipLaunchKernelGGL(shift_threshold_kernel<M>, grid, block, 0, st, s.ctls, n_queries, dim, s.thr, \
-                                         padded, s.dyn_lvl, s.dyn_lad, s.dyn_cnt)
-    if (metric == TRAG_COSINE) TRAG_SHIFT(0);
-    else if (metric == TRAG_EUCLIDEAN) TRAG_SHIFT(1);
-    else TRAG_SHIFT(2);
-#undef TRAG_SHIFT
+// n_maxima: tile maxima per query the sample pass wrote (one per 32 sampled rows)
+void launch_tau_shift(uint32_t metric, const Bf16Scratch& s, uint32_t n_maxima, uint32_t n_queries, uint32_t padded,
+                      uint32_t dim, hipStream_t st) {
+    const dim3 grid(n_queries + (padded - n_queries + TAU_THREADS - 1) / TAU_THREADS), block(TAU_THREADS);
+#define TRAG_TAU(M) hipLaunchKernelGGL(tau_shift_kernel<M>, grid, block, 0, st, s.tmax, s.tmax_stride, n_maxima, s.ctls, \
+                                       n_queries, padded, dim, s.thr, s.dyn_lvl, s.dyn_lad, s.dyn_cnt)
+    if (metric == TRAG_COSINE) TRAG_TAU(0);
+    else if (metric == TRAG_EUCLIDEAN) TRAG_TAU(1);
+    else TRAG_TAU(2);
+#undef TRAG_TAU
 }
 
 // Which of the two forms serves a batch. The query-stationary form (trag_qstat.hip) reads the

@@ -194,8 +194,6 @@ hipError_t launch_batch_finish(const float* d_Q, uint32_t n_queries, const ScanA
 hipError_t launch_bf16_prep(const float* d_Q, uint32_t n_queries, uint32_t padded, const ScanArgs& a,
                             const float* d_norm2, const Bf16Scratch& s, uint32_t need, uint32_t k,
                             const float* d_vmax_sq, bool with_rowc, hipStream_t st);
-void launch_tau_select(const uint32_t* tmax, size_t tmax_stride, uint32_t n_tiles64, SearchCtl* ctls,
-                       uint32_t n_queries, hipStream_t st);
 // bf16 prefilter (trag_bf16.hip) and its exact finish (trag_kernels.hip)
 bool bf16_supports(uint32_t dim, uint32_t metric);
 uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim);

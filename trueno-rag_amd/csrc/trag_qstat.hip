@@ -637,17 +637,93 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
 // The full pass may have raised the query's threshold along its ladder (trag_device.h): the rows
 // left out of the list are then only known to lie below that raised value, and the final check
 // must be made against it.
-// (256 threads: the lists are a few hundred entries long, and four times as many workgroups fit a CU as
-// with 1024 -- what the stage costs is the latency of its loads and barriers, not its work.)
+// The list is ranked by counting: a thread keeps its E entries in registers and counts, over all
+// the list's keys in LDS, the entries that sort before each (larger value first, earlier entry
+// first among equals) -- two barriers where a sorting network for 256 entries takes 36, and 32 KB of
+// LDS where the network's keys and the rows took 48 KB, three workgroups to a CU.
+// The survivors -- a prefix of the sorted order -- land where the sort would have put them.
+// (256 threads: the lists are a few hundred entries long, and four times as many workgroups fit a CU
+// as with 1024 -- what the stage costs is the latency of its loads and barriers, not its work.)
 constexpr int PRUNE_THREADS = 256;
+
+template <int METRIC, int E>
+__device__ __forceinline__ void prune_list(SearchCtl* __restrict__ ctl, uint32_t* __restrict__ cq,
+                                           const uint32_t* __restrict__ vq, float* __restrict__ thr_y, uint32_t d,
+                                           uint32_t C, uint32_t need, float na, float na_sq, float tv_cur,
+                                           unsigned long long* keys_sh, uint32_t* shared3) {
+    const int tid = threadIdx.x;
+    // an entry's sort key: its value's ordered key, then earlier entries first -- unique, so one
+    // 64-bit comparison per pair ranks the list (the counting is the stage's arithmetic: every
+    // thread against every entry)
+    unsigned long long key[E];
+    uint32_t row[E], above[E];
+    uint32_t n_inf = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)e * PRUNE_THREADS;
+        key[e] = 0ull;
+        row[e] = 0u;
+        above[e] = 0u;
+        if (i < C) {
+            const float v = __uint_as_float(vq[i]);
+            row[e] = cq[i];
+            // +inf and NaN sort first: they are kept whatever the threshold
+            const uint32_t k32 = (v != v || v == INFINITY) ? 0xFFFFFFFFu : score_key(v);
+            n_inf += k32 == 0xFFFFFFFFu;
+            key[e] = ((unsigned long long)k32 << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+            keys_sh[i] = key[e];
+        }
+    }
+    if (n_inf) atomicAdd(&shared3[0], n_inf);
+    __syncthreads();
+    const uint32_t F = shared3[0];
+    if (F + need > C) return;   // fewer than `need` rows with a usable score: keep the whole list
+    for (uint32_t j = 0; j < C; ++j) {
+        const unsigned long long o = keys_sh[j];
+#pragma unroll
+        for (int e = 0; e < E; ++e) above[e] += o > key[e] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if ((uint32_t)tid + (uint32_t)e * PRUNE_THREADS < C && above[e] == F + need - 1u) shared3[2] = (uint32_t)(key[e] >> 32);
+    __syncthreads();
+    // A = the need-th largest usable value; the lowered threshold, in score space (t, for the final
+    // check) and in v space (tv)
+    const float A = key_score(shared3[2]);
+    const float vmax = sqrtf(ctl->vmax_sq);
+    const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
+    float t, tv;
+    if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
+    else if (METRIC == 1) { t = (A - na_sq) - 2.02f * eps; tv = t + na_sq; }
+    else { t = A - 2.02f * eps; tv = t; }
+    if (!(t == t) || !(tv == tv) || !(tv > tv_cur)) return;   // nothing gained (or out of range): keep the list
+    const uint32_t tkey = score_key(tv);
+    uint32_t kept = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)e * PRUNE_THREADS;
+        if (i < C && (uint32_t)(key[e] >> 32) >= tkey) {
+            cq[above[e]] = row[e];   // (every thread read its rows before the first barrier)
+            ++kept;
+        }
+    }
+    if (kept) atomicAdd(&shared3[1], kept);
+    __syncthreads();
+    if (tid == 0) {
+        ctl->cand_count = shared3[1];
+        ctl->t_key = score_key(t);
+        *thr_y = tv;
+    }
+}
+
 template <int METRIC>
 __global__ void __launch_bounds__(PRUNE_THREADS)
 qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const uint32_t* __restrict__ cvals,
                 float* __restrict__ thr, uint32_t d, const uint32_t* __restrict__ dyn_lvl,
                 const float* __restrict__ dyn_lad) {
-    __shared__ unsigned long long sk[CAND_CAP];
-    __shared__ uint32_t rows[CAND_CAP];
-    __shared__ uint32_t n_inf_sh, keep_sh;
+    __shared__ unsigned long long keys_sh[CAND_CAP];
+    __shared__ uint32_t shared3[3];   // rows kept whatever the threshold, survivors, A's key
+    static_assert(CAND_CAP <= 16 * PRUNE_THREADS, "entries per thread");
     const int tid = threadIdx.x;
     const uint32_t y = blockIdx.x;
     SearchCtl* ctl = ctls + y;
@@ -671,124 +747,11 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     if (C > CAND_CAP || C <= need) return;
     uint32_t* cq = cand + (size_t)y * CAND_CAP;
     const uint32_t* vq = cvals + (size_t)y * CAND_CAP;
-    if (tid == 0) { n_inf_sh = 0; keep_sh = 0; }
+    if (tid == 0) { shared3[0] = 0; shared3[1] = 0; }
     __syncthreads();
-    if (C <= 2u * PRUNE_THREADS) {
-        // Lists of a few hundred entries (the usual case) are ranked by counting: every thread
-        // counts, for its one or two entries, the entries that sort before them -- two barriers where
-        // a sorting network for 256 entries takes 36 (the stage's time: 29 us for 1000 queries
-        // with lists of ~150). The survivors land where the sort would have put them.
-        unsigned long long mine[2];
-        uint32_t n_inf = 0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)e * PRUNE_THREADS;
-            mine[e] = 0ull;
-            if (i < C) {
-                const float v = __uint_as_float(vq[i]);
-                rows[i] = cq[i];
-                const uint32_t key = (v != v || v == INFINITY) ? 0xFFFFFFFFu : score_key(v);
-                n_inf += key == 0xFFFFFFFFu;
-                mine[e] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - i);
-                sk[i] = mine[e];
-            }
-        }
-        if (n_inf) atomicAdd(&n_inf_sh, n_inf);
-        __syncthreads();
-        const uint32_t F = n_inf_sh;
-        if (F + need > C) return;   // fewer than `need` rows with a usable score: keep the whole list
-        uint32_t above[2] = {0u, 0u};
-        for (uint32_t j = 0; j < C; ++j) {
-            const unsigned long long o = sk[j];
-            above[0] += o > mine[0];
-            above[1] += o > mine[1];
-        }
-        // (entry i has rank above[e] in descending order; the padding entries of a thread, 0, rank last)
-        __shared__ uint32_t a_key_sh;
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-            if ((uint32_t)tid + (uint32_t)e * PRUNE_THREADS < C && above[e] == F + need - 1u) a_key_sh = (uint32_t)(mine[e] >> 32);
-        __syncthreads();
-        const float A = key_score(a_key_sh);
-        const float vmax = sqrtf(ctl->vmax_sq);
-        const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
-        float t, tv;
-        if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
-        else if (METRIC == 1) { t = (A - na_sq) - 2.02f * eps; tv = t + na_sq; }
-        else { t = A - 2.02f * eps; tv = t; }
-        if (!(t == t) || !(tv == tv) || !(tv > tv_cur)) return;   // nothing gained (or out of range): keep the list
-        const uint32_t tkey = score_key(tv);
-        uint32_t kept = 0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)e * PRUNE_THREADS;
-            if (i < C && (uint32_t)(mine[e] >> 32) >= tkey) {
-                cq[above[e]] = rows[i];
-                ++kept;
-            }
-        }
-        if (kept) atomicAdd(&keep_sh, kept);
-        __syncthreads();
-        if (tid == 0) {
-            ctl->cand_count = keep_sh;
-            ctl->t_key = score_key(t);
-            thr[y] = tv;
-        }
-        return;
-    }
-    uint32_t P = 64;
-    while (P < C) P <<= 1;
-    uint32_t n_inf = 0;
-    for (uint32_t i = tid; i < P; i += (uint32_t)PRUNE_THREADS) {
-        unsigned long long e = 0ull;
-        if (i < C) {
-            const float v = __uint_as_float(vq[i]);
-            rows[i] = cq[i];
-            // +inf and NaN sort first: they are kept whatever the threshold
-            const uint32_t key = (v != v || v == INFINITY) ? 0xFFFFFFFFu : score_key(v);
-            n_inf += key == 0xFFFFFFFFu;
-            e = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - i);
-        }
-        sk[i] = e;
-    }
-    if (n_inf) atomicAdd(&n_inf_sh, n_inf);
-    for (uint32_t size = 2; size <= P; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (uint32_t i = tid; i < P / 2; i += (uint32_t)PRUNE_THREADS) {
-                const uint32_t pos = 2 * i - (i & (stride - 1));
-                const unsigned long long a = sk[pos], b = sk[pos + stride];
-                const bool desc = (pos & size) == 0;
-                if (desc ? (a < b) : (a > b)) { sk[pos] = b; sk[pos + stride] = a; }
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t F = n_inf_sh;
-    if (F + need > C) return;   // fewer than `need` rows with a usable score: keep the whole list
-    const float A = key_score((uint32_t)(sk[F + need - 1] >> 32));
-    // the lowered threshold, in score space (t, for the final check) and in v space (tv)
-    const float vmax = sqrtf(ctl->vmax_sq);
-    const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
-    float t, tv;
-    if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
-    else if (METRIC == 1) { t = (A - na_sq) - 2.02f * eps; tv = t + na_sq; }
-    else { t = A - 2.02f * eps; tv = t; }
-    if (!(t == t) || !(tv == tv) || !(tv > tv_cur)) return;   // nothing gained (or out of range): keep the list
-    const uint32_t tkey = score_key(tv);
-    // the survivors are a prefix of the sorted list
-    uint32_t mine = 0;
-    for (uint32_t i = tid; i < C; i += (uint32_t)PRUNE_THREADS) mine += (uint32_t)(sk[i] >> 32) >= tkey;
-    if (mine) atomicAdd(&keep_sh, mine);
-    __syncthreads();
-    const uint32_t keep = keep_sh;
-    for (uint32_t i = tid; i < keep; i += (uint32_t)PRUNE_THREADS)
-        cq[i] = rows[0xFFFFFFFFu - (uint32_t)(sk[i] & 0xFFFFFFFFull)];
-    if (tid == 0) {
-        ctl->cand_count = keep;
-        ctl->t_key = score_key(t);
-        thr[y] = tv;
-    }
+    if (C <= (uint32_t)PRUNE_THREADS) prune_list<METRIC, 1>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys_sh, shared3);
+    else if (C <= 2u * PRUNE_THREADS) prune_list<METRIC, 2>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys_sh, shared3);
+    else prune_list<METRIC, 16>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys_sh, shared3);
 }
 
 bool qs_supports(uint32_t dim, uint32_t metric) {
@@ -868,8 +831,8 @@ uint32_t qs_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
 }
 
 // declared in trag_bf16.hip
-void launch_shift_threshold(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t padded, uint32_t dim,
-                            hipStream_t st);
+void launch_tau_shift(uint32_t metric, const Bf16Scratch& s, uint32_t n_maxima, uint32_t n_queries, uint32_t padded,
+                      uint32_t dim, hipStream_t st);
 
 void launch_qs_prune(uint32_t metric, const Bf16Scratch& s, uint32_t n_queries, uint32_t dim, hipStream_t st) {
     if (metric == TRAG_COSINE)
@@ -892,8 +855,7 @@ hipError_t launch_qs_scan(uint32_t n_queries, const ScanArgs& a, const uint16_t*
     else qs_launch<0, false>(n_queries, a, d_mirror, d_norm2, s, step, need, st);
     const uint32_t n_tiles = (a.n_rows + RT - 1) / RT;
     const uint32_t sampled = (n_tiles + step - 1) / step;
-    launch_tau_select(s.tmax, s.tmax_stride, sampled * (RT / 32), s.ctls, n_queries, st);
-    launch_shift_threshold(a.metric, s, n_queries, padded, a.dim, st);
+    launch_tau_shift(a.metric, s, sampled * (RT / 32), n_queries, padded, a.dim, st);
     if (d_mirror) qs_launch<1, true>(n_queries, a, d_mirror, d_norm2, s, 1, need, st);
     else qs_launch<1, false>(n_queries, a, d_mirror, d_norm2, s, 1, need, st);
     launch_qs_prune(a.metric, s, n_queries, a.dim, st);
