@@ -25,6 +25,8 @@ __device__ __forceinline__ void prep_query(const float* __restrict__ q, uint32_t
     __shared__ __attribute__((aligned(16))) float qs[4096];
     __shared__ float err_sh[4];
     const int tid = threadIdx.x;
+    // (asked for here, not where thread 0 uses them after the sum: one round trip less at the end)
+    const float vmax0 = vmax_sq ? vmax_sq[0] : 0.0f, vmax1 = vmax_sq ? vmax_sq[1] : 1.0f;
     float acc = 0.0f;
     float e2 = 0.0f;   // sum of (bf16(q) - q)^2, for the bf16 prefilter's bound (any order)
     for (uint32_t base = 0; base < d; base += 4096) {
@@ -39,6 +41,9 @@ __device__ __forceinline__ void prep_query(const float* __restrict__ q, uint32_t
         __syncthreads();
         if (tid == 0) {
             uint32_t i = 0;
+            // (unrolled so that the LDS reads of eight steps are in flight together: one thread alone
+            // otherwise waits out an LDS latency per four components)
+#pragma unroll 8
             for (; i + 4 <= len; i += 4) {
                 const v4f x = *reinterpret_cast<const v4f*>(&qs[i]);
                 float p0 = x.x * x.x, p1 = x.y * x.y, p2 = x.z * x.z, p3 = x.w * x.w;
@@ -60,8 +65,8 @@ __device__ __forceinline__ void prep_query(const float* __restrict__ q, uint32_t
     if (tid == 0) {
         ctl->na_sq = acc;
         ctl->na = sqrtf(acc);
-        ctl->vmax_sq = vmax_sq ? vmax_sq[0] : 0.0f;
-        ctl->rho = bf16_operand_rho((err_sh[0] + err_sh[1]) + (err_sh[2] + err_sh[3]), acc, vmax_sq ? vmax_sq[1] : 1.0f);
+        ctl->vmax_sq = vmax0;
+        ctl->rho = bf16_operand_rho((err_sh[0] + err_sh[1]) + (err_sh[2] + err_sh[3]), acc, vmax1);
         ctl->need = need;
         ctl->k = k;
         ctl->resolved = 1;  // the threshold comes from tau_select_kernel, not from histograms
