@@ -160,3 +160,20 @@ def test_rows_at_the_formats_worst_case_move_the_bound(trag, oracle, d, B):
     full = np.concatenate([corpus, extra])
     for kk in (k, 3):
         check(store, oracle, full, Q, kk, 0, "worst-case rows", rows=[0, 1, 2, 3, B - 1])
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_long_candidate_lists_are_pruned_exactly(trag, oracle, metric):
+    """Many wanted rows per query and a batch of only a few workgroups: the candidate lists of the
+    full pass run past 512 entries (printed by a TRAG_LIST_DIAG build: 530-800 here),
+    the regime where the prune stage selects its threshold by radix levels and ranks only the
+    survivors. Rows and score bits must still be the oracle's, for every k."""
+    rng = np.random.default_rng(31 + metric)
+    n, d, B = 300_000, 128, 160
+    corpus = unit_rows(rng, n, d) if metric != 2 else rng.standard_normal((n, d)).astype(np.float32)
+    Q = unit_rows(rng, B, d)
+    store = make_store(trag, d, metric)
+    store.insert_rows(corpus)
+    for k in (100, 200):
+        check(store, oracle, corpus, Q, k, metric, f"long lists metric {metric}", rows=[0, 1, 2, 77, B - 1],
+              modes=(BF16, MFMA))

@@ -38,50 +38,8 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int BF_K = 64;   // f32 columns staged per step (= 4 MFMA k-steps of 16)
 constexpr int BF_LD = 36;  // dwords per LDS row: 64 bf16 + 4 dwords of padding (conflict-free b128 reads)
 
-// find_bin over a 2048-bin histogram in LDS, called by all 256 threads of the workgroup: the highest
-// bin whose suffix count reaches `need`, and the count strictly above it. sh: 6 words.
 constexpr int TAU_THREADS = 256;
-__device__ __forceinline__ void find_bin_256(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
-                                             uint32_t* sh) {
-    static_assert(HIST_BINS == 8 * TAU_THREADS, "eight bins per thread");
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int top = (int)HIST_BINS - 1 - 8 * t;  // thread t owns bins top, top - 1, ..., top - 7
-    uint32_t h[8], sum = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        h[i] = hist[top - i];
-        sum += h[i];
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) sh[w] = incl;
-    if (t == 0) { sh[4] = 0; sh[5] = 0; }
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i < w) base += sh[i];
-        total += sh[i];
-    }
-    incl += base;
-    if (need > total) need = total;
-    uint32_t run = incl - sum;
-    if (need > 0 && run < need && need <= incl) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (run < need && run + h[i] >= need) { sh[4] = (uint32_t)(top - i); sh[5] = run; }
-            run += h[i];
-        }
-    }
-    __syncthreads();
-    bin = sh[4];
-    above = sh[5];
-    __syncthreads();
-}
+static_assert(HIST_BINS == 2048u, "find_bin_256 assumes 2048 bins");
 
 // Between the sample pass and the full pass, one workgroup per query.
 // First the query's threshold in key space: the need-th largest of the sample's tile maxima (at

@@ -64,6 +64,49 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
+// find_bin over a 2048-bin histogram in LDS, called by all 256 threads of the workgroup: the highest
+// bin whose suffix count reaches `need`, and the count strictly above it. sh: 6 words.
+__device__ __forceinline__ void find_bin_256(const uint32_t* hist, uint32_t need, uint32_t& bin, uint32_t& above,
+                                             uint32_t* sh) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int top = 2047 - 8 * t;  // thread t owns bins top, top - 1, ..., top - 7
+    uint32_t h[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = hist[top - i];
+        sum += h[i];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) sh[w] = incl;
+    if (t == 0) { sh[4] = 0; sh[5] = 0; }
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < w) base += sh[i];
+        total += sh[i];
+    }
+    incl += base;
+    if (need > total) need = total;
+    uint32_t run = incl - sum;
+    if (need > 0 && run < need && need <= incl) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (run < need && run + h[i] >= need) { sh[4] = (uint32_t)(top - i); sh[5] = run; }
+            run += h[i];
+        }
+    }
+    __syncthreads();
+    bin = sh[4];
+    above = sh[5];
+    __syncthreads();
+}
+
 // bf16 prefilter: largest |approximate - reference| of a score, as a multiple of
 // the scale ||q|| * ||v|| (cosine: of 1). With q' and v' the operands rounded to bf16,
 //   |sum q'v' - sum qv| = |q'.(v' - v) + (q' - q).v| <= ||q'|| ||v' - v|| + ||q' - q|| ||v||

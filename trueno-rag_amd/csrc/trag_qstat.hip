@@ -718,14 +718,109 @@ __device__ __forceinline__ void prune_list(SearchCtl* __restrict__ ctl, uint32_t
     }
 }
 
+// Lists longer than 512 entries (small batches, whose few workgroups raise the thresholds late, and
+// clustered corpora): counting every entry against every other would cost more than the sort it
+// replaced (1.25 M x 384, 256 queries, lists of ~800: 81 us against 28). Instead A is found by three
+// radix levels over the keys in LDS, as the thresholds are, and only the survivors -- the rows at or
+// above the lowered threshold, a few tens -- are ranked by counting. More than 512 survivors: the
+// list is left as it is (it is still every row above the threshold the pass used).
+constexpr uint32_t PRUNE_SURV = 512;
+template <int METRIC>
+__device__ __forceinline__ void prune_long_list(SearchCtl* __restrict__ ctl, uint32_t* __restrict__ cq,
+                                                const uint32_t* __restrict__ vq, float* __restrict__ thr_y,
+                                                uint32_t d, uint32_t C, uint32_t need, float na, float na_sq,
+                                                float tv_cur, uint32_t* keys32, uint32_t* hist,
+                                                unsigned long long* surv_key, uint32_t* surv_row,
+                                                uint32_t* shared3, uint32_t* sh6) {
+    const int tid = threadIdx.x;
+    uint32_t n_inf = 0;
+    for (uint32_t i = (uint32_t)tid; i < C; i += (uint32_t)PRUNE_THREADS) {
+        const float v = __uint_as_float(vq[i]);
+        const uint32_t k32 = (v != v || v == INFINITY) ? 0xFFFFFFFFu : score_key(v);
+        n_inf += k32 == 0xFFFFFFFFu;
+        keys32[i] = k32;
+    }
+    if (n_inf) atomicAdd(&shared3[0], n_inf);
+    __syncthreads();
+    const uint32_t F = shared3[0];
+    if (F + need > C) return;   // fewer than `need` rows with a usable score: keep the whole list
+    // the (F + need)-th largest key (the rows kept whatever the threshold carry the largest key)
+    uint32_t want = F + need, prefix = 0, prefix_bits = 0;
+    const int shifts[3] = {21, 10, 0};
+    const uint32_t widths[3] = {11, 11, 10};
+#pragma unroll
+    for (int level = 0; level < 3; ++level) {
+        for (int i = tid; i < 2048; i += PRUNE_THREADS) hist[i] = 0u;
+        __syncthreads();
+        const uint32_t mshift = 32u - prefix_bits;
+        const uint32_t shift = (uint32_t)shifts[level], mask = (1u << widths[level]) - 1u;
+        for (uint32_t i = (uint32_t)tid; i < C; i += (uint32_t)PRUNE_THREADS) {
+            const uint32_t k32 = keys32[i];
+            if (prefix_bits == 0 || (k32 >> mshift) == prefix) atomicAdd(&hist[(k32 >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        uint32_t bin, above;
+        find_bin_256(hist, want, bin, above, sh6);
+        want -= above;
+        prefix = (prefix << widths[level]) | bin;
+        prefix_bits += widths[level];
+    }
+    const float A = key_score(prefix);
+    const float vmax = sqrtf(ctl->vmax_sq);
+    const float eps = bf16_eps<METRIC>(d, na, vmax, ctl->rho);
+    float t, tv;
+    if (METRIC == 0) { t = A / na - 2.02f * eps; tv = t * na; }
+    else if (METRIC == 1) { t = (A - na_sq) - 2.02f * eps; tv = t + na_sq; }
+    else { t = A - 2.02f * eps; tv = t; }
+    if (!(t == t) || !(tv == tv) || !(tv > tv_cur)) return;   // nothing gained (or out of range): keep the list
+    const uint32_t tkey = score_key(tv);
+    for (uint32_t i = (uint32_t)tid; i < C; i += (uint32_t)PRUNE_THREADS) {
+        const uint32_t k32 = keys32[i];
+        if (k32 >= tkey) {
+            const uint32_t pos = atomicAdd(&shared3[1], 1u);
+            if (pos < PRUNE_SURV) {
+                surv_key[pos] = ((unsigned long long)k32 << 32) | (unsigned long long)(0xFFFFFFFFu - i);
+                surv_row[pos] = cq[i];
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t S = shared3[1];
+    if (S > PRUNE_SURV) return;   // (nothing has been written yet)
+    // every thread holds its survivors' rows before any is written back
+    unsigned long long mine[2];
+    uint32_t row[2], above2[2] = {0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)e * PRUNE_THREADS;
+        mine[e] = i < S ? surv_key[i] : 0ull;
+        row[e] = i < S ? surv_row[i] : 0u;
+    }
+    for (uint32_t j = 0; j < S; ++j) {
+        const unsigned long long o = surv_key[j];
+        above2[0] += o > mine[0] ? 1u : 0u;
+        above2[1] += o > mine[1] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        if ((uint32_t)tid + (uint32_t)e * PRUNE_THREADS < S) cq[above2[e]] = row[e];
+    if (tid == 0) {
+        ctl->cand_count = S;
+        ctl->t_key = score_key(t);
+        *thr_y = tv;
+    }
+}
+
 template <int METRIC>
 __global__ void __launch_bounds__(PRUNE_THREADS)
 qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const uint32_t* __restrict__ cvals,
                 float* __restrict__ thr, uint32_t d, const uint32_t* __restrict__ dyn_lvl,
                 const float* __restrict__ dyn_lad) {
-    __shared__ unsigned long long keys_sh[CAND_CAP];
+    // short lists: 512 packed keys; long lists: 4096 keys, a histogram, the survivors' keys and rows
+    __shared__ __attribute__((aligned(8))) uint32_t lds[CAND_CAP + 2048 + 2 * PRUNE_SURV + PRUNE_SURV];
     __shared__ uint32_t shared3[3];   // rows kept whatever the threshold, survivors, A's key
-    static_assert(CAND_CAP <= 16 * PRUNE_THREADS, "entries per thread");
+    __shared__ uint32_t sh6[6];
+    static_assert(2 * 2 * PRUNE_THREADS <= CAND_CAP + 2048 + 3 * PRUNE_SURV, "short-list keys fit");
     const int tid = threadIdx.x;
     const uint32_t y = blockIdx.x;
     SearchCtl* ctl = ctls + y;
@@ -751,9 +846,13 @@ qs_prune_kernel(SearchCtl* __restrict__ ctls, uint32_t* __restrict__ cand, const
     const uint32_t* vq = cvals + (size_t)y * CAND_CAP;
     if (tid == 0) { shared3[0] = 0; shared3[1] = 0; }
     __syncthreads();
-    if (C <= (uint32_t)PRUNE_THREADS) prune_list<METRIC, 1>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys_sh, shared3);
-    else if (C <= 2u * PRUNE_THREADS) prune_list<METRIC, 2>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys_sh, shared3);
-    else prune_list<METRIC, 16>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys_sh, shared3);
+    unsigned long long* keys64 = reinterpret_cast<unsigned long long*>(lds);
+    if (C <= (uint32_t)PRUNE_THREADS) prune_list<METRIC, 1>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys64, shared3);
+    else if (C <= 2u * PRUNE_THREADS) prune_list<METRIC, 2>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, keys64, shared3);
+    else
+        prune_long_list<METRIC>(ctl, cq, vq, thr + y, d, C, need, na, na_sq, tv_cur, lds, lds + CAND_CAP,
+                                reinterpret_cast<unsigned long long*>(lds + CAND_CAP + 2048),
+                                lds + CAND_CAP + 2048 + 2 * PRUNE_SURV, shared3, sh6);
 }
 
 bool qs_supports(uint32_t dim, uint32_t metric) {
