@@ -473,6 +473,9 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     } else {
         // hits are rare (a few hundred rows per query and million rows): first one fma and one
         // compare per accumulator into a per-lane bit mask, then a loop over the set bits
+        // (what the listing costs the full pass, measured with thresholds no row reaches: 1 M x 768,
+        // 256 queries, 693 -> 665 us from f32 rows, 485 -> 459 from the mirror -- one round trip of
+        // returning atomics at the end of a workgroup's life, half hidden by the CU's other workgroup)
         uint32_t wmask[TM];
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
