@@ -943,6 +943,8 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
 // the candidates to stay within the lower half: callers use it when at most
 // CAND_CAP / 2 rows can qualify, and the wave-by-wave form below otherwise.
 // All 1024 threads must call it; ends with a barrier.
+// (Asking for ALL tile maxima at the kernel's start, beside the histogram -- 20 per thread at 1.25 M
+// rows -- and so skipping the level of the wave maxima measured no gain: 17.2 against 16.9 us.)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void gather_flat(uint32_t lo, uint32_t hi, bool rows_only, uint32_t n_rows,
                                             uint32_t n_tiles, uint32_t n_waves, uint32_t my_wmax,
