@@ -379,7 +379,9 @@ MFMA = 3
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("n,d,B", [(50_000, 768, 40), (33_333, 384, 130), (20_000, 128, 300), (30_000, 256, 9),
-                                   (25_001, 384, 32), (20_000, 64, 64)])
+                                   (25_001, 384, 32), (20_000, 64, 64),
+                                   # an odd number of 32-column chunks: the exact re-score's last, unpaired chunk
+                                   (20_000, 96, 20), (20_000, 160, 12), (20_000, 32, 10)])
 def test_batch_mfma_parity(trag, oracle, n, d, B, metric):
     rng = np.random.default_rng(n + d + B)
     corpus = unit_rows(rng, n, d) if metric == 0 else rng.standard_normal((n, d)).astype(np.float32)
