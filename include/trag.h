@@ -143,7 +143,10 @@ trag_status trag_store_search_batch(trag_store *s, const float *queries, uint32_
  * host memory whenever a query reports 3, the next call reads it (no
  * synchronisation), and once at least 4 queries and half of those enqueued so
  * far reported 3 the multi-level select becomes the plan. A caller that enqueues
- * hundreds of queries ahead of the GPU sees this take effect that much later. */
+ * hundreds of queries ahead of the GPU sees this take effect that much later.
+ * Euclidean stores of fewer than about 1.8 M rows start on the multi-level select
+ * (distances between normalised vectors crowd one bin as a rule; the form costs a
+ * few microseconds there), so they do not go through this learning at all. */
 trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint32_t n_queries,
                                      uint32_t dim, uint32_t k, uint32_t *d_out_rows,
                                      float *d_out_scores, uint32_t *d_out_n,
