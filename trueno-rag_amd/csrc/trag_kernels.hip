@@ -1853,7 +1853,11 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
         // 64-float chunks 6.44 (with 2 / 3 waves per CU 5.93 / 6.26), default-policy instead of
         // non-temporal loads 5.94; buffer loads with any of the sc0 / sc1 / nt policies at best 6.25 (nt)).
         // Short scans agree: 1 M x 384 with 1 / 2 / 3 workgroups per CU 0.2375 / 0.243 / 0.259 ms, 1.25 M
-        // 0.295 / 0.3015 / 0.3256.
+        // 0.295 / 0.3015 / 0.3256. Very short ones (10 k - 500 k rows) are their bytes at the streaming
+        // rate plus some 12 us that do not shrink: a variant with four chunks of loads in flight per wave
+        // and the query in LDS instead of the scalar cache, with up to three workgroups per CU, moved
+        // 10 k rows from 16.8 to 15.1 us, 100 k from 34.7 to 32.6 (22 us of it the bytes), 250 k and 500 k
+        // not at all, and was not kept.
         static int n_cu = 0;
         if (n_cu == 0) {
             int dev = 0;
