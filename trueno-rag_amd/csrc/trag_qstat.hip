@@ -35,7 +35,9 @@
 // later move costs is thresholds that lag (1.25 M x 384 x 1000 queries, ms per step on one device:
 // 8 entries 1.323, 16 1.299, 32 1.288; with the tighter bound 16 1.260, 48 1.232; the full pass alone,
 // later: 48 entries 1.096, 64 1.112, 96 1.113, 128 1.118 -- and 1.013 with thresholds no row reaches:
-// what the pass lists costs it a tenth of its time, most of it these stalls). Moving the lists
+// what the pass lists costs it a tenth of its time; not the drain after the stores, though: with the
+// stores issued by inline assembly, which the compiler's wait counting does not see, and no drain, the
+// pass took 1.072-1.081 ms against 1.072-1.075). Moving the lists
 // at the END of a tile, where wave 0 -- the older wave of its SIMD, done with its steps before the
 // younger ones -- would otherwise idle at the barrier, measured no better: 1.220 against 1.213.
 #ifndef QS_FLUSH_MIN
