@@ -69,7 +69,7 @@ __device__ __forceinline__ void prep_query(const float* __restrict__ q, uint32_t
         ctl->rho = bf16_operand_rho((err_sh[0] + err_sh[1]) + (err_sh[2] + err_sh[3]), acc, vmax1);
         ctl->need = need;
         ctl->k = k;
-        ctl->resolved = 1;  // the threshold comes from tau_select_kernel, not from histograms
+        ctl->resolved = 1;  // the threshold comes from the tile maxima (tau_select_kernel / tau_shift_kernel), not from histograms
         ctl->b1 = ctl->above1 = ctl->b2 = ctl->above2 = 0;
         ctl->t_key = 0;
         ctl->cut_ties = 0;

@@ -260,7 +260,7 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         if (i == 0)
             pre_rc[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rowc_g) + (size_t)row0 * 8u + rc_off);
     };
-    // (scale, shift): see qs_rowc_kernel
+    // (scale, shift): see row_scale_shift (trag_device.h)
     auto write_piece = [&](int k, int i, int sl, uint32_t) __attribute__((always_inline)) {
         if (MIR) {
             *reinterpret_cast<u32x4*>(&img[sl][loff[i]]) = pre[k][i];
