@@ -37,7 +37,13 @@
 // later: 48 entries 1.096, 64 1.112, 96 1.113, 128 1.118 -- and 1.013 with thresholds no row reaches:
 // what the pass lists costs it a tenth of its time; not the drain after the stores, though: with the
 // stores issued by inline assembly, which the compiler's wait counting does not see, and no drain, the
-// pass took 1.072-1.081 ms against 1.072-1.075). Moving the lists
+// pass took 1.072-1.081 ms against 1.072-1.075). With a ladder that never moves (more than twice the
+// hits) the mirror pass takes 1.094 ms, 1.029 when the flush then drops the lists instead of writing
+// them, 0.846 without any hit: three quarters of what listing costs is the listing itself -- a wave
+// that has a hit runs some hundred instructions between two MFMAs, and the other seven meet it at the
+// tile's barrier, nearly every tile -- and a quarter the flush. (Counting a strong row for levels
+// spread down to the known one, instead of the four just below its own, changed neither the lists --
+// 200-270 entries -- nor the time.) Moving the lists
 // at the END of a tile, where wave 0 -- the older wave of its SIMD, done with its steps before the
 // younger ones -- would otherwise idle at the barrier, measured no better: 1.220 against 1.213.
 #ifndef QS_FLUSH_MIN
