@@ -43,7 +43,8 @@
 // that has a hit runs some hundred instructions between two MFMAs, and the other seven meet it at the
 // tile's barrier, nearly every tile -- and a quarter the flush. (Counting a strong row for levels
 // spread down to the known one, instead of the four just below its own, changed neither the lists --
-// 200-270 entries -- nor the time.) Moving the lists
+// 200-270 entries -- nor the time; nor did a raised priority, until the tile's barrier, for the wave that
+// lists: 0.944 / 0.947 against 0.937 / 0.940 ms.) Moving the lists
 // at the END of a tile, where wave 0 -- the older wave of its SIMD, done with its steps before the
 // younger ones -- would otherwise idle at the barrier, measured no better: 1.220 against 1.213.
 #ifndef QS_FLUSH_MIN
