@@ -189,6 +189,26 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         for (int ks = 0; ks < KS; ++ks)
             qa[qb][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qp + ks * 16));
     }
+#ifndef QS_PIN_KS0
+#define QS_PIN_KS0 64
+#endif
+#ifdef QS_PIN_AGPR
+    // One wave per SIMD (512 registers): the query fragments live in the accumulation half of the
+    // register file for the whole kernel and the MFMAs read them there (their A / B operands may be
+    // AGPRs on gfx950). Left to itself the compiler parks them there too -- as spills, and copies four
+    // registers back in front of every MFMA.
+    if (NW == 4) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (qb == 0 && ks >= QS_PIN_KS0) continue;
+                u32x4 t = __builtin_bit_cast(u32x4, qa[qb][ks]);
+                asm volatile("" : "=a"(t) : "0"(t));
+                qa[qb][ks] = __builtin_bit_cast(bf16x8, t);
+            }
+    }
+#endif
     // accumulator register rr of block qb of lane (r, h) belongs to query q0 + 32 qb + qrow(rr) and corpus
     // row r of the subtile; e = 16 qb + rr numbers a lane's accumulators
     auto qrow = [&](int rr) __attribute__((always_inline)) { return (uint32_t)((rr & 3) + 8 * (rr >> 2) + 4 * h); };
@@ -520,7 +540,13 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                 uint32_t total = 0u;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) total += (uint32_t)__builtin_amdgcn_readlane((int)fill, w);
+#ifdef QS_FLUSH_EARLY
+                // the first tiles of a stream run on the sample's thresholds, the loosest of the pass: what
+                // they list reaches the ladder's counters at once
+                if (total >= (n < (uint32_t)QS_FLUSH_EARLY ? 4u : (uint32_t)QS_FLUSH_MIN)) flush(half ^ 1);
+#else
                 if (total >= (uint32_t)QS_FLUSH_MIN) flush(half ^ 1);
+#endif
             }
             load_thresholds();
         }
@@ -534,7 +560,11 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
             const int it = 1 + (sub + DP) / NSUB, isub = (sub + DP) % NSUB;   // tile ahead / subtile of the load
             const uint32_t row0 = unit[0] * rows_per_unit + 32u * (uint32_t)sub;
             const uint32_t row0_write = unit[1] * rows_per_unit + 32u * (uint32_t)sub;
+#ifdef QS_EXP_SAMETILE
+            const uint32_t row0_issue = 32u * (uint32_t)isub + 0u * unit[it];   // (every load hits L2: latency ablation)
+#else
             const uint32_t row0_issue = unit[it] * rows_per_unit + 32u * (uint32_t)isub;
+#endif
 #ifdef QS_PRIO
             // the two waves of a SIMD take turns at being preferred by the issue arbiter (which, left
             // alone, always prefers the older one: waves 0..3). (Measured without effect, as was one
@@ -555,10 +585,12 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                 for (int qb = 0; qb < QB; ++qb)
                     acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[qb][ks], fr[ks % NF], acc[qb], 0, 0, 0);
                 if (ks + NF < KS) fr[ks % NF] = frag(sl, ks + NF);
+#ifndef QS_EXP_NOSTAGE
                 if (ks % PER == PER - 1) {
                     write_piece(ring, ks / PER, wsl, row0_write);
                     issue_piece(ring, ks / PER, row0_issue);
                 }
+#endif
             };
             // (two loops, so that the listing of hits is not part of a loop body: with it inside, the
             // body times its trip count passes the size up to which the compiler unrolls fully, and the
@@ -566,14 +598,21 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
 #pragma unroll
             for (int ks = 0; ks < (MODE == 1 ? NCH : 0); ++ks) {
                 k_step(ks);
+#ifndef QS_EXP_NOTEST
                 test_some(accp, scp, ks * CH, CH, mp);
+#endif
                 // (pins this piece of the test to this k-step: without it the compiler sinks all the
                 // pieces to the point where the running maximum is used and runs them in one burst
                 // between two MFMAs)
                 asm volatile("" :: "v"(mp[(ks * CH) >> 2]));
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef QS_EXP_NOTEST
             if (MODE == 1) list_hits(accp, scp, shp, mp, row0p, half);
+#elif defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) asm volatile("" :: "v"(accp[qb]));   // (keeps the products alive)
+#endif
 #pragma unroll
             for (int ks = (MODE == 1 ? NCH : 0); ks < KS; ++ks) {
                 k_step(ks);
@@ -916,13 +955,21 @@ static void qs_launch_one(uint32_t n_queries, const ScanArgs& a, const uint16_t*
 #ifndef QS_DP_A
 #define QS_DP_A 1
 #endif
+// d = 384: waves per workgroup (8: two per SIMD, one block of 32 queries each; 4: one per SIMD with
+// the 512-register budget, two blocks each) and staging depth
+#ifndef QS_NW_384
+#define QS_NW_384 8
+#endif
+#ifndef QS_DP_384
+#define QS_DP_384 QS_DP_A
+#endif
 template <int MODE, bool MIR>
 static void qs_launch(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
                       const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st) {
     switch (a.dim) {
     case 128: qs_launch_one<8, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st); break;
     case 256: qs_launch_one<16, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st); break;
-    case 384: qs_launch_one<24, 8, 1, 64, MODE, MIR, QS_DP_A>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st); break;
+    case 384: qs_launch_one<24, QS_NW_384, 8 / QS_NW_384, 64, MODE, MIR, QS_DP_384>(n_queries, a, d_mirror, d_norm2, s, tile_step, need, st); break;
     default: break;   // (qs_supports: the caller never comes here with another dimension)
     }
 }
