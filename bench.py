@@ -69,7 +69,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (inside a profiler session the preloaded library has already initialised the GPU in this
+    # process, and a GPU-initialised process must not start other programs)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
+        n.startswith(("ROCPROF", "ROCP_")) for n in os.environ)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if profiled:
+            sys.exit("bench.py --gpus N under a profiler: this process may not start the ranks (the profiler has "
+                     "initialised the GPU in it). Profile one rank (--gpus 1 --rows <rows per GPU>), or start the "
+                     "ranks with torch.distributed.run outside the profiler.")
         # started as plain `python bench.py --gpus N`: launch the N ranks (one process per GPU) as
         # children of this process, which has not touched the GPU, and hand their exit code on
         import socket
@@ -86,11 +94,7 @@ def main():
     import torch.distributed as dist
     # HBM traffic of the scan kernel from the hardware counters: a short copy of this very run
     # under rocprofv3, started before this process touches the GPU
-    traffic = None
-    # (never from inside a profiler session: its preloaded library has already initialised the GPU
-    # in this process, and a GPU-initialised process must not start other programs)
-    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(
-        n.startswith(("ROCPROF", "ROCP_")) for n in os.environ)
+    traffic = None   # (never from inside a profiler session, see above)
     if (world == 1 and not args.no_pmc and not args.hybrid and not args.host and not profiled
             and not os.environ.get("TRAG_BENCH_CHILD")):
         traffic = pmc_traffic(args)
@@ -110,13 +114,20 @@ def main():
     pkg = load_package()
     L = pkg.lib()
 
+    # A rank stuck in the communicator's set-up or in a collective must not sit there until somebody's
+    # timeout: with more than one rank (or TRAG_BENCH_DEBUG) every stage of the run re-arms a watchdog
+    # that prints the stack of the stuck rank -- the line it is stuck on -- and exits non-zero.
+    watchdog_s = float(os.environ.get("TRAG_BENCH_WATCHDOG_S", "300"))
+    watched = world > 1 or bool(os.environ.get("TRAG_BENCH_DEBUG"))
+    if watched:
+        import faulthandler
+
     def stage(msg):
+        if watched:
+            faulthandler.dump_traceback_later(watchdog_s, exit=True)
         if os.environ.get("TRAG_BENCH_DEBUG"):
             print(f"[debug] rank {rank}: {msg}", file=sys.stderr, flush=True)
 
-    if os.environ.get("TRAG_BENCH_DEBUG"):   # a stuck run names the line it is stuck on, then exits
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ.get("TRAG_BENCH_WATCHDOG_S", "600")), exit=True)
     stage("process group up")
     n_total, d, k = args.rows, args.dim, args.k
     per = (n_total + world - 1) // world
@@ -245,7 +256,10 @@ def main():
     fence()
     stage("warmup done")
     # an event pair costs ~6 us of stream time: on sub-millisecond scans time every 4th launch only
-    store.set_profiling(0 if os.environ.get("TRAG_BENCH_NO_PROFILE") else (4 if args.steps >= 40 else 1))
+    prof_every = 4 if args.steps >= 40 else 1
+    # (hybrid: BM25 runs beside the scan on a second stream, and an event pair around the scan then also
+    # spans whatever of the previous step is still draining: the scan is timed alone, after the steps)
+    store.set_profiling(0 if (os.environ.get("TRAG_BENCH_NO_PROFILE") or args.hybrid) else prof_every)
     import gc
     gc.collect()
     gc.disable()   # as timeit does: a generation-2 collection of this process's heap is a ~70 ms pause
@@ -264,6 +278,15 @@ def main():
     stage("timed steps done")
     if os.environ.get("TRAG_BENCH_DEBUG"):
         print(f"[debug] loop {1e3 * t_loop:.2f} ms, fence {1e3 * (elapsed - t_loop):.2f} ms", file=sys.stderr)
+    if args.hybrid and not os.environ.get("TRAG_BENCH_NO_PROFILE"):
+        # the dense scan of the last steps' queries once more, alone on the stream, every launch timed
+        prof_every = 1
+        store.set_profiling(1)
+        for i in range(max(args.warmup, args.warmup + args.steps - 10), args.warmup + args.steps):
+            store.search_device(Q.data_ptr() + i * d * esz, 1, cand, h_rows.data_ptr() + i * cand * esz,
+                                h_scores.data_ptr() + i * cand * esz, out_n.data_ptr() + i * esz,
+                                status.data_ptr() + i * esz, sptr)
+        torch.cuda.synchronize()
     scan_ms, scan_launches = store.scan_time()
     store.set_profiling(False)
     mode_used = store.last_stats()["mode_used"]  # the path the timed steps actually took
@@ -271,10 +294,24 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    batch_leg = None
+    batch_leg, batch_sample = None, None
     if (group is not None or ex is not None) and not args.hybrid and B != 1000:
-        batch_leg = exchange_batch_leg(args, store, group, ex, side if ex is not None else None, rank, world, row0,
-                                       d, k, seed, sptr, stream, fence, dist)
+        stage("second leg: 1000 queries per step")
+        batch_leg, batch_sample = exchange_batch_leg(args, store, group, ex, side if ex is not None else None, rank,
+                                                     world, row0, d, k, seed, sptr, stream, fence, dist)
+    # what RCCL itself says about the communicator of every rank (evidence that the exchange ran over
+    # `world` ranks, one GPU each)
+    ranks_info = None
+    if group is not None:
+        try:
+            mine_info = dict(group.info(), rank=rank, local_device=local)
+        except Exception as e:  # noqa: BLE001 -- an RCCL without the query calls: say so in the record
+            mine_info = {"rank": rank, "local_device": local, "error": str(e)}
+        ranks_info = [mine_info]
+        if world > 1:
+            ranks_info = [None] * world
+            dist.all_gather_object(ranks_info, mine_info)
+    stage("parity checks")
 
     # ---- parity at full size (outside the timed region) ----
     uncertified = int((status[args.warmup * B:] != 0).sum().item())
@@ -325,6 +362,16 @@ def main():
         parity["device_merge_equals_host_merge"] = bool(
             np.array_equal(g_rows[order], final_rows.astype(np.int64)[:len(order)])
             and g_scores[order].tobytes() == final_scores[:len(order)].tobytes())
+    if sharded and not args.hybrid and rank == 0:
+        # The sharded result against ONE store that holds the whole corpus on this rank's GPU (exact-order
+        # scan: another route than the shards' automatic one), bit for bit: the last queries of the
+        # headline leg and a sample of the 1000-query leg. And, as on the single-GPU line, the library
+        # against the CPU oracle on the first rows of the corpus.
+        nv = min(8, args.steps * B)
+        head = (Q[n_q - nv:].cpu().numpy(), m_rows[n_q - nv:].cpu().numpy().astype(np.uint32),
+                m_scores[n_q - nv:].cpu().numpy(), m_n[n_q - nv:].cpu().numpy(), status[n_q - nv:].cpu().numpy())
+        parity.update(single_store_check(pkg, local, n_total, d, k, seed, metric_id, head, batch_sample,
+                                         args.cpu_sample_rows, with_oracle=not args.no_cpu_baseline))
     if world == 1 and not sharded:
         # the exact-order scan of the same query must return the same rows and score bits
         store.set_scan_mode(1)
@@ -349,7 +396,7 @@ def main():
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
         # corpus passes per step, from the library's own count of timed scans (the bf16 prefilter
         # takes up to 2048 queries a pass in its query-stationary form and 256 in its tiled form)
-        passes = max(1, round(scan_launches / max(args.steps, 1)))
+        passes = 1 if args.hybrid else max(1, round(scan_launches * prof_every / max(args.steps, 1)))
         b_launch = B / passes                                   # queries served by one scan launch
         flops = 2.0 * b_launch * n_local * d
         tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
@@ -381,6 +428,9 @@ def main():
                                     "all-gather (version %d), merge on every rank; exchange of step i overlaps "
                                     "the scan of step i+1" % rccl_version_or_zero()) if group is not None else
                                    ("Python ShardExchange over gloo (rehearsal)" if ex is not None else None),
+                       "rccl_version": rccl_version_or_zero() if group is not None else None,
+                       "rccl_comm_world": (ranks_info[0].get("comm_world") if ranks_info else None),
+                       "ranks": ranks_info,
                        "scan_mode": {0: "auto", 1: "exact", 2: "stream", 3: "mfma", 4: "bf16-prefilter", 5: "bf16-mirror"}[args.mode],
                        "bf16_mirror": bool(args.mirror),
                        "entry": "host pointers (PCIe + synchronisation inside every step)" if args.host
@@ -419,7 +469,13 @@ def main():
         result["roofline"].update({"kernel": "scan (corpus pass)", "kernel_avg_ms": scan_avg_ms,
                                    "launches_timed": scan_launches, "queries_per_launch": b_launch,
                                    "algorithmic_bytes_per_launch": algo_bytes,
-                                   "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9})
+                                   "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
+                                   # a kernel cannot take longer than the step that contains it: if the event
+                                   # brackets say so, they measured something else and `frac` is not evidence
+                                   "timing_inconsistent": bool(scan_avg_ms * passes > ms_per_step * 1.0005)})
+        if args.hybrid:
+            result["roofline"]["kernel_timed"] = ("the dense scan alone on the stream (no BM25 beside it), the last "
+                                                  "steps' queries again after the timed region")
         if world == 1 and not args.hybrid and not args.mirror and args.mode == 0 and not args.host:
             result["with_bf16_mirror"] = mirror_leg(store, args, Q, out_rows, out_scores, out_n, status, n_local, d,
                                                     B, k, esz, sptr)
@@ -493,10 +549,14 @@ def exchange_batch_leg(args, store, group, ex, side, rank, world, row0, d, k, se
         dist.all_gather_object(all_d, digest)
         same = all(x == all_d[0] for x in all_d)
     sc = scores[-1].cpu().numpy()
-    return {"value": steps * BX / elapsed, "unit": "queries/s", "batch": BX, "steps": steps,
-            "ms_per_step": 1e3 * elapsed / steps, "unfinished_queries": unfinished,
-            "sorted": bool(np.all(sc[:-1] >= sc[1:])), "all_ranks_hold_the_same_lists": bool(same),
-            "path_used": store.last_stats()["mode_used"]}
+    # the first 32 queries of the last step with their merged lists, for the single-store check
+    lo = (warm + steps - 1) * BX
+    sample = (Q[lo:lo + 32].cpu().numpy(), rows[lo:lo + 32].cpu().numpy().astype(np.uint32),
+              scores[lo:lo + 32].cpu().numpy(), cnt[lo:lo + 32].cpu().numpy(), status[lo:lo + 32].cpu().numpy())
+    return ({"value": steps * BX / elapsed, "unit": "queries/s", "batch": BX, "steps": steps,
+             "ms_per_step": 1e3 * elapsed / steps, "unfinished_queries": unfinished,
+             "sorted": bool(np.all(sc[:-1] >= sc[1:])), "all_ranks_hold_the_same_lists": bool(same),
+             "path_used": store.last_stats()["mode_used"]}, sample)
 
 
 def mirror_leg(store, args, Q, out_rows, out_scores, out_n, status, n_local, d, B, k, esz, sptr):
@@ -626,29 +686,87 @@ def cpu_baseline(store, Q, n_local, n_total, d, k, sample_rows, seed, first_glob
         oracle.search(sample, qs[i], k, metric_id)
         t.append(time.perf_counter() - t0)
     fast = sorted(t)[1] * (n_total / m)
-    # parity against the oracle at the sample's size: a second store holding the same first m rows
-    # (the generator is a pure function of (seed, row)), every mode the bench can use
-    pkg = load_package()
-    sub = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, metric=pkg.DistanceMetric(metric_id),
-                                                device=store.config().device, reserve_rows=m))
-    sub.fill_synthetic(m, seed, first_global_row=first_global_row)
-    same_rows, max_diff, ties = True, 0.0, 0
-    for i in range(n_q):
-        er, es = oracle.search(sample, qs[i], k, metric_id)
-        gr, gs = sub.search_rows(qs[i], k)
-        same_rows = same_rows and np.array_equal(gr, er)
-        max_diff = max(max_diff, float(np.max(np.abs(gs - es))) if len(es) else 0.0)
-        ties += int(np.sum(es[1:] == es[:-1]))
-    sub.close()
     return {"value": 1.0 / per_query_full, "unit": "queries/s", "cores": 1, "kind": "port",
             "sample": f"first {m} rows of the corpus, {n_q} queries, median seconds/query {sec:.4f}, "
                       f"scaled linearly to {n_total} rows",
             "host_cpus_visible": os.cpu_count(),
-            "parity_vs_oracle": {"rows": m, "queries": n_q, "k": k, "ranks_identical": bool(same_rows),
-                                 "max_abs_score_diff": max_diff, "exact_score_ties_seen": ties},
+            "parity_vs_oracle": oracle_parity(sample, qs, d, k, seed, first_global_row, metric_id,
+                                              store.config().device),
             "not_the_reference": {"what": "contiguous layout, row loop over all host threads (OpenMP), partial "
                                           "selection; same f32 arithmetic",
                                   "value": 1.0 / fast, "unit": "queries/s", "threads": oracle.num_threads()}}
+
+
+def oracle_parity(sample, qs, d, k, seed, first_global_row, metric_id, device):
+    """The library against the CPU oracle at the sample's size: a second store that holds the same m rows
+    (the generator is a pure function of (seed, row)), searched through the automatic routing."""
+    from oracle import oracle
+    pkg = load_package()
+    m, n_q = sample.shape[0], qs.shape[0]
+    sub = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, metric=pkg.DistanceMetric(metric_id),
+                                                device=device, reserve_rows=m))
+    sub.fill_synthetic(m, seed, first_global_row=first_global_row)
+    same_rows, same_bits, max_diff, ties = True, True, 0.0, 0
+    for i in range(n_q):
+        er, es = oracle.search(sample, qs[i], k, metric_id)
+        gr, gs = sub.search_rows(qs[i], k)
+        same_rows = same_rows and np.array_equal(gr, er)
+        same_bits = same_bits and gs.tobytes() == es.tobytes()
+        max_diff = max(max_diff, float(np.max(np.abs(gs - es))) if len(es) == len(gs) and len(es) else 0.0)
+        ties += int(np.sum(es[1:] == es[:-1]))
+    sub.close()
+    return {"rows": m, "queries": n_q, "k": k, "ranks_identical": bool(same_rows), "score_bits_identical": bool(same_bits),
+            "max_abs_score_diff": max_diff, "exact_score_ties_seen": ties}
+
+
+def single_store_check(pkg, device, n_total, d, k, seed, metric_id, head, batch_sample, oracle_rows, with_oracle=True):
+    """Rank 0 of a sharded run: the whole corpus once more in ONE store on this GPU, scanned in the
+    reference's order (scan mode `exact`), and the sharded run's merged lists compared with its
+    results bit for bit -- rows, score bits and counts. `head`: (queries, rows, scores, counts,
+    statuses) of the headline leg's last queries; `batch_sample`: the same of the 1000-query leg."""
+    out = {}
+    need = n_total * d * 4 * 1.12 + n_total * 16 + (1 << 28)
+    free, _ = torch.cuda.mem_get_info()
+    if free < need:
+        out["sharded_equals_single_store"] = None
+        out["single_store_check_skipped"] = f"{free / 1e9:.1f} GB free on rank 0's GPU, the whole corpus needs {need / 1e9:.1f}"
+        return out
+    t0 = time.perf_counter()
+    full = pkg.VectorStore(pkg.VectorStoreConfig(dimension=d, metric=pkg.DistanceMetric(metric_id), device=device,
+                                                 scan_mode=1, reserve_rows=n_total))
+    full.fill_synthetic(n_total, seed, first_global_row=0)
+
+    def same(sample):
+        qs, rows, scores, counts, statuses = sample
+        fr, fs, fn = full.search_batch_rows(qs, k)
+        ok, checked, unfinished = True, 0, 0
+        for b in range(qs.shape[0]):
+            if statuses[b] != 0:       # a query the device entry left unfinished is counted, not compared
+                unfinished += 1
+                continue
+            n = int(fn[b])
+            ok = ok and int(counts[b]) == n and np.array_equal(rows[b, :n], fr[b, :n]) \
+                and scores[b, :n].tobytes() == fs[b, :n].tobytes()
+            checked += 1
+        return ok, checked, unfinished
+
+    ok_h, n_h, u_h = same(head)
+    detail = {"whole_corpus_rows": n_total, "route": "exact-order scan of one store on rank 0's GPU",
+              "headline_queries_compared": n_h, "headline_identical": bool(ok_h), "unfinished_skipped": u_h}
+    ok = ok_h and n_h > 0
+    if batch_sample is not None:
+        ok_b, n_b, u_b = same(batch_sample)
+        detail.update({"batch_1000_queries_compared": n_b, "batch_1000_identical": bool(ok_b)})
+        detail["unfinished_skipped"] += u_b
+        ok = ok and ok_b and n_b > 0
+    out["sharded_equals_single_store"] = bool(ok)
+    if with_oracle:
+        m = min(oracle_rows, n_total)
+        out["parity_vs_oracle"] = oracle_parity(full.read_rows(0, m), head[0], d, k, seed, 0, metric_id, device)
+    full.close()
+    detail["seconds"] = time.perf_counter() - t0
+    out["single_store_check"] = detail
+    return out
 
 
 if __name__ == "__main__":

@@ -279,7 +279,9 @@ void trag_shard_group_destroy(trag_shard_group *g);
  * enqueues local search -> records -> all-gather -> merge; every rank receives the global top k
  * (global row ids) in its own d_out_* arrays. d_status[b] (optional) is the worst status any
  * shard reported for query b (codes of trag_store_search_device): non-zero asks for
- * trag_shard_search_batch. Device pointers, no synchronisation. */
+ * trag_shard_search_batch. Device pointers, no synchronisation. A rank whose local search fails
+ * still joins the all-gather (with empty records that carry status 3) before it returns its error,
+ * so its peers are not left waiting in the collective. */
 trag_status trag_shard_search_device(trag_shard_group *g, trag_store *local, uint32_t row0, uint32_t row_mul,
                                      const float *d_queries, uint32_t n_queries, uint32_t dim, uint32_t k,
                                      uint32_t *d_out_rows, float *d_out_scores, uint32_t *d_out_n,
@@ -293,6 +295,12 @@ trag_status trag_shard_search_batch(trag_shard_group *g, trag_store *local, uint
                                     uint32_t *out_rows, float *out_scores, uint32_t *out_n);
 /* NCCL-style version code of the RCCL in use (e.g. 22707). */
 trag_status trag_shard_rccl_version(int *version);
+/* What the group's RCCL communicator reports about itself (ncclCommCount, ncclCommUserRank,
+ * ncclCommCuDevice): the number of ranks it spans, this rank's number in it and the device it is bound
+ * to -- evidence, for a benchmark record, that the exchange really ran over `world` ranks. Any
+ * output pointer may be NULL. TRAG_UNSUPPORTED when the RCCL in use lacks those calls. */
+trag_status trag_shard_group_info(trag_shard_group *g, uint32_t *comm_world, uint32_t *comm_rank,
+                                  int32_t *comm_device);
 
 /* (b) One process, n GPUs: a VectorStore striped over device_ids[0..n_devices) -- global row g
  * lives on shard g % n as local row g / n, so appends keep the shards level, global row ids

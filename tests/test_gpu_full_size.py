@@ -44,6 +44,30 @@ def test_c2_1m_x_384_against_oracle(trag, oracle):
         assert_same_ranking(rows[b], scores[b], er, es, f"C2 batch {b}")
 
 
+@pytest.mark.parametrize("metric", [1, 2])
+def test_c2_1m_x_384_euclidean_and_dot_against_oracle(trag, oracle, metric):
+    """The other two DistanceMetrics (src/index.rs:398-402) at C2's size, single queries, every route
+    a single query can take (automatic, exact, streaming) and a small batch, k = 10 and 50."""
+    n, d = 1_000_000, 384
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(metric), reserve_rows=n))
+    store.fill_synthetic(n, 1002)
+    corpus = oracle.synth_rows(1002, 0, n, d)
+    Q = oracle.synth_rows(1102, 0, 3, d) * np.float32(1.5 if metric == 2 else 1.0)
+    for mode in (0, EXACT, STREAM):
+        store.set_scan_mode(mode)
+        for q in Q:
+            for k in (10, 50):
+                rows, scores = store.search_rows(q, k)
+                er, es = oracle.search(corpus, q, k, metric)
+                assert_same_ranking(rows, scores, er, es, f"C2 metric={metric} mode={mode} k={k}")
+    store.set_scan_mode(0)
+    Qb = oracle.synth_rows(1103, 0, 12, d)
+    rows, scores, cnt = store.search_batch_rows(Qb, 50)
+    for b in (0, 5, 11):
+        er, es = oracle.search(corpus, Qb[b], 50, metric)
+        assert_same_ranking(rows[b], scores[b], er, es, f"C2 metric={metric} batch {b}")
+
+
 @pytest.mark.parametrize("n,d", [(10_000_000, 384), (2_000_000, 4096)])
 def test_large_corpus_properties(trag, oracle, n, d):
     store = _store(trag, d, n)
@@ -113,6 +137,21 @@ def test_batch_configs_against_oracle(trag, oracle, n, d, B, seed):
     store.set_scan_mode(EXACT)
     r8, s8, _ = store.search_batch_rows(Q[:8], 10)
     assert np.array_equal(r8, rows[:8]) and s8.tobytes() == scores[:8].tobytes()
+    # the reference's own k: the pipeline asks every source for 50 (src/retrieve.rs:94,176), its bench
+    # for 100 (benches/retrieval.rs:89-91). All queries across the three batch routes, a handful against
+    # the oracle.
+    for k in (50, 100):
+        res = {}
+        for mode in (0, 3, 4):
+            store.set_scan_mode(mode)
+            res[mode] = store.search_batch_rows(Q, k)
+            assert store.last_stats()["mode_used"] == (4 if mode == 0 else mode)
+        for mode in (3, 4):
+            assert np.array_equal(res[0][0], res[mode][0]) and res[0][1].tobytes() == res[mode][1].tobytes()
+        assert res[0][2].tolist() == [k] * B
+        for b in (0, 1, B // 2, B - 1):
+            er, es = oracle.search(corpus, Q[b], k, 0)
+            assert_same_ranking(res[0][0][b], res[0][1][b], er, es, f"batch config n={n} q={b} k={k}")
 
 
 @pytest.mark.parametrize("n,d,k", [(10_000_000, 384, 10), (2_000_000, 4096, 50)])

@@ -85,6 +85,7 @@ SIGNATURES = {
     "trag_shard_search_batch": (C.c_int, [_H, _H, C.c_uint32, C.c_uint32, _fp, C.c_uint32, C.c_uint32, C.c_uint32,
                                           _u32p, _fp, _u32p]),
     "trag_shard_rccl_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "trag_shard_group_info": (C.c_int, [_H, _u32p, _u32p, C.POINTER(C.c_int32)]),
     "trag_sharded_create": (C.c_int, [C.POINTER(Config), C.c_uint32, C.POINTER(C.c_int32), C.c_uint32,
                                       C.POINTER(_H)]),
     "trag_sharded_destroy": (None, [_H]),

@@ -55,6 +55,10 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
+    // what a communicator says about itself (optional symbols: absent -> trag_shard_group_info says so)
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
 };
 
 // Loads RCCL once per process. TRAG_RCCL_LIB names a file to use instead of the search below.
@@ -88,7 +92,10 @@ const Rccl& rccl() {
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
         r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
-        if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+        if (!ok) { dlclose(r.handle); r.handle = nullptr; return; }
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.handle, "ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(r.handle, "ncclCommUserRank"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(dlsym(r.handle, "ncclCommCuDevice"));
     });
     return r;
 }
@@ -282,20 +289,47 @@ trag_status trag_shard_search_device(trag_shard_group* g, trag_store* local, uin
     g->next ^= 1u;
     // the exchange that used this slot two calls ago may still be reading it on the side stream
     if (sl.used) SH_TRY(hipStreamWaitEvent(st, sl.done, 0));
-    ts = trag_store_search_device(local, d_queries, n_queries, dim, k, sl.rows, sl.scores, sl.n, sl.status, st);
-    if (ts != TRAG_OK) return ts;
+    // A rank whose local search cannot be enqueued still takes part in the collective -- its peers have
+    // entered it or are about to, and an all-gather one rank never joins hangs them all: it sends
+    // records that hold no row and carry status 3, so every rank sees the query as unfinished, and
+    // this rank returns its error once the exchange is enqueued.
+    const trag_status local_ts =
+        trag_store_search_device(local, d_queries, n_queries, dim, k, sl.rows, sl.scores, sl.n, sl.status, st);
+    const std::string local_msg = local_ts != TRAG_OK ? std::string(trag_last_error()) : std::string();
     hipStream_t xs = st;
     if (g->cfg.overlap) {
         SH_TRY(hipEventRecord(sl.searched, st));
         SH_TRY(hipStreamWaitEvent(g->side, sl.searched, 0));
         xs = g->side;
     }
-    SH_TRY(launch_pack_topk(sl.rows, sl.scores, sl.n, row0, n_queries, k, sl.pack, xs, row_mul ? row_mul : 1u, sl.status));
     const size_t words = (size_t)n_queries * rec_words(k);
+    if (local_ts == TRAG_OK)
+        SH_TRY(launch_pack_topk(sl.rows, sl.scores, sl.n, row0, n_queries, k, sl.pack, xs, row_mul ? row_mul : 1u, sl.status));
+    else   // every word (ST_NEED_REFINE << 16) | 0: read as a count word, no rows and that status
+        SH_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(sl.pack), (int)(ST_NEED_REFINE << 16), words, xs));
     NCCL_TRY(R, R->AllGather(sl.pack, sl.gathered, words, ncclUint32, g->comm, xs));
     SH_TRY(launch_merge_packed(sl.gathered, g->cfg.world, n_queries, k, d_out_rows, d_out_scores, d_out_n, xs, d_status));
     SH_TRY(hipEventRecord(sl.done, xs));
     sl.used = true;
+    if (local_ts != TRAG_OK) return set_error(local_ts, "local search of this rank failed (the exchange was still joined): " + local_msg);
+    return TRAG_OK;
+}
+
+trag_status trag_shard_group_info(trag_shard_group* g, uint32_t* comm_world, uint32_t* comm_rank, int32_t* comm_device) {
+    if (!g) return set_error(TRAG_INVALID_ARG, "null group");
+    const Rccl* R = nullptr;
+    trag_status ts = need_rccl(&R);
+    if (ts != TRAG_OK) return ts;
+    if (!R->CommCount || !R->CommUserRank || !R->CommCuDevice)
+        return set_error(TRAG_UNSUPPORTED, "this RCCL exports no ncclCommCount / ncclCommUserRank / ncclCommCuDevice");
+    std::lock_guard<std::mutex> lk(g->mu);
+    int n = 0, r = 0, d = 0;
+    NCCL_TRY(R, R->CommCount(g->comm, &n));
+    NCCL_TRY(R, R->CommUserRank(g->comm, &r));
+    NCCL_TRY(R, R->CommCuDevice(g->comm, &d));
+    if (comm_world) *comm_world = (uint32_t)n;
+    if (comm_rank) *comm_rank = (uint32_t)r;
+    if (comm_device) *comm_device = d;
     return TRAG_OK;
 }
 
@@ -537,6 +571,15 @@ trag_status trag_sharded_insert(trag_sharded_store* s, const float* rows, uint64
     if (s->n_rows + n > 0xFFFFFFF0ull) return set_error(TRAG_INVALID_ARG, "row count exceeds u32 row ids");
     if (out_first_row) *out_first_row = (uint32_t)s->n_rows;
     if (n == 0) return TRAG_OK;
+    // room on every shard first: a shard that cannot grow (out of memory on one GPU) must fail the call
+    // before any other shard has appended its stripe, or the shards would be out of step for good
+    for (uint32_t j = 0; j < s->G; ++j) {
+        uint64_t i0 = 0, cnt = 0;
+        stripe(s->n_rows, n, s->G, j, &i0, &cnt);
+        if (cnt == 0) continue;
+        trag_status tr = trag_store_reserve(s->dev[j].store, trag_store_rows(s->dev[j].store) + cnt);
+        if (tr != TRAG_OK) return tr;
+    }
     std::vector<float> mine;
     for (uint32_t j = 0; j < s->G; ++j) {
         uint64_t i0 = 0, cnt = 0;

@@ -74,6 +74,8 @@ extern "C" {
                                     hip_stream: *mut c_void) -> i32;
     pub fn trag_shard_fence(g: *mut TragShardGroup, hip_stream: *mut c_void) -> i32;
     pub fn trag_shard_rccl_version(version: *mut i32) -> i32;
+    pub fn trag_shard_group_info(g: *mut TragShardGroup, comm_world: *mut u32, comm_rank: *mut u32,
+                                 comm_device: *mut i32) -> i32;
 }
 
 fn err(code: i32, expected: usize, actual: usize) -> Error {

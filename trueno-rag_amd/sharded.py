@@ -242,6 +242,12 @@ class ShardGroup:
             C.c_void_p(d_rows_ptr), C.c_void_p(d_scores_ptr), C.c_void_p(d_n_ptr),
             C.c_void_p(d_status_ptr) if d_status_ptr else None, C.c_void_p(stream) if stream else None), dim, dim)
 
+    def info(self):
+        """What the RCCL communicator says about itself: ranks it spans, this rank, its device."""
+        w, r, d = C.c_uint32(), C.c_uint32(), C.c_int32()
+        _abi.check(_abi.lib().trag_shard_group_info(self._h, C.byref(w), C.byref(r), C.byref(d)))
+        return {"comm_world": w.value, "comm_rank": r.value, "comm_device": d.value}
+
     def fence(self, stream: int = 0):
         _abi.check(_abi.lib().trag_shard_fence(self._h, C.c_void_p(stream) if stream else None))
 
