@@ -162,7 +162,12 @@ trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint
  * stream creation. Limits: at most 16 777 216 rows ever inserted in the store and k <= 4064
  * (unless the store holds <= 4096 live rows), else TRAG_UNSUPPORTED. All calls on one GPU share
  * that GPU's array, across stores: calls whose GPU work overlaps (two streams, two threads with
- * two stores) race and return garbage -- keep them on one stream or order them with events. */
+ * two stores) race and return garbage -- keep them on one stream or order them with events.
+ * Under stream capture (hipStreamBeginCapture on hip_stream) the call records its launches and
+ * memsets into the graph and touches no other stream; a replay with other queries in the same
+ * device buffers returns what the call itself would. Rows inserted since the handle's last search
+ * make a captured call TRAG_UNSUPPORTED (run one search outside the capture first), and the
+ * handle does not order its later calls behind replays: that is the caller's. */
 trag_status trag_store_search_device_noalloc(trag_store *s, const float *d_queries,
                                              uint32_t n_queries, uint32_t dim, uint32_t k,
                                              uint32_t *d_out_rows, float *d_out_scores,

@@ -104,3 +104,34 @@ def test_sparse_key_stores_change_nothing(trag, oracle, metric):
     # the switch did something: a bound was in force for a random query, in both scans, and none without
     assert gathered["1", EXACT] > 0x007FFFFF and gathered["1", MIRROR] > 0x007FFFFF, gathered
     assert gathered["0", EXACT] == 0 and gathered["0", MIRROR] == 0, gathered
+
+
+def test_euclidean_long_store_finishes_queries_enqueued_far_ahead(trag, oracle):
+    """A 2.7 M-row Euclidean store of normalised vectors: nearly every distance shares the coarse score
+    bin of the k-th best, which the one-workgroup select used to hand back (status 3) until the handle
+    had learned the multi-level plan -- every query enqueued before that came back unfinished. With the
+    sparse key stores the scan's own bound cuts the crowd: 200 queries enqueued ahead of the GPU, on a
+    fresh handle, all finish, with the oracle's rows and score bits."""
+    import torch
+    n, d, k, B = 2_700_000, 64, 10, 200
+    st = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(1), device=0, reserve_rows=n))
+    st.fill_synthetic(n, 31)
+    Q = oracle.synth_rows(32, 0, B, d)
+    dq = torch.from_numpy(Q).cuda()
+    rows = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+    scores = torch.zeros((B, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    status = torch.full((B,), 9, dtype=torch.int32, device="cuda")
+    sp = torch.cuda.current_stream().cuda_stream
+    for b in range(B):      # one query per call, nothing synchronised in between
+        st.search_device(dq.data_ptr() + b * d * 4, 1, k, rows.data_ptr() + b * k * 4, scores.data_ptr() + b * k * 4,
+                         cnt.data_ptr() + b * 4, status.data_ptr() + b * 4, sp)
+    torch.cuda.synchronize()
+    assert int((status != 0).sum().item()) == 0, status.tolist()
+    assert cnt.tolist() == [k] * B
+    corpus = oracle.synth_rows(31, 0, n, d)
+    for b in (0, 1, 99, 199):
+        er, es = oracle.search(corpus, Q[b], k, 1)
+        assert_same_ranking(rows[b].cpu().numpy().astype(np.uint32), scores[b].cpu().numpy(), er, es, f"query {b}")
+    # the crowd really is there: without the bound the one-workgroup select gives up
+    st.close()

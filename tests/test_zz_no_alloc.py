@@ -112,3 +112,67 @@ def test_noalloc_limits_and_edge_cases(trag, oracle):
                                                    C.c_void_p(n.data_ptr()), None, None), d, d + 1)
     st.close()
     empty.close()
+
+
+def test_noalloc_first_call_on_a_short_euclidean_store(trag, oracle):
+    """The no-allocation entry decides the select plan as the regular one does: a short Euclidean store
+    (distances between normalised vectors crowd one coarse score bin) searched ONLY through it finishes
+    every query, from the first one, with the oracle's rows and score bits."""
+    import torch
+    d, n = 64, 30_000
+    st = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(1), device=0, reserve_rows=n))
+    st.fill_synthetic(n, 99)
+    Q = oracle.synth_rows(98, 0, 4, d)
+    dq = torch.from_numpy(Q).cuda()
+    rows = torch.zeros((4, 10), dtype=torch.int32, device="cuda")
+    scores = torch.zeros((4, 10), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+    status = torch.full((4,), 9, dtype=torch.int32, device="cuda")
+    st.search_device_noalloc(dq.data_ptr(), 4, 10, rows.data_ptr(), scores.data_ptr(), cnt.data_ptr(),
+                             status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert status.tolist() == [0, 0, 0, 0] and cnt.tolist() == [10] * 4
+    corpus = st.read_rows(0, n)
+    for b in range(4):
+        er, es = oracle.search(corpus, Q[b], 10, 1)
+        assert_same_ranking(rows[b].cpu().numpy().astype(np.uint32), scores[b].cpu().numpy(), er, es, f"query {b}")
+    st.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_noalloc_captured_in_a_graph_and_replayed(trag, oracle, metric):
+    """One call captured into a HIP graph on a store long enough for the sparse key stores (2M x 64:
+    30 tiles per scan wave), then replayed with other queries in the same device buffer: every replay
+    must return what the regular entry returns for those queries (a tag or a bound that survived from
+    one replay to the next would make the select skip rows it needs)."""
+    import torch
+    d, n, k, B = 64, 2_000_000, 10, 2
+    st = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(metric), device=0,
+                                                 scan_mode=1, reserve_rows=n))
+    st.fill_synthetic(n, 4243)
+    Qs = oracle.synth_rows(9100, 0, 4 * B, d).reshape(4, B, d)
+    dq = torch.from_numpy(Qs[0].copy()).cuda()
+    rows = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+    scores = torch.zeros((B, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    status = torch.full((B,), 9, dtype=torch.int32, device="cuda")
+    # one regular search first: the store's derived data are up to date, nothing is pending
+    st.search_rows(Qs[0][0], k)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st.search_device_noalloc(dq.data_ptr(), B, k, rows.data_ptr(), scores.data_ptr(), cnt.data_ptr(),
+                                 status.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for rep in range(4):
+        dq.copy_(torch.from_numpy(Qs[rep].copy()))
+        rows.zero_(); scores.zero_(); cnt.zero_(); status.fill_(9)
+        graph.replay()
+        torch.cuda.synchronize()
+        got = (rows.cpu().numpy().astype(np.uint32), scores.cpu().numpy(), cnt.cpu().numpy(), status.cpu().numpy())
+        assert got[3].tolist() == [0] * B and got[2].tolist() == [k] * B, (rep, got[2], got[3])
+        for b in range(B):
+            er, es = st.search_rows(Qs[rep][b], k)      # the regular (host) entry, exact scan
+            assert_same_ranking(got[0][b], got[1][b], er, es, f"replay {rep}, query {b}")
+    # the sparse key stores were in force in the captured scans: the regular entry reports the bound
+    assert st.last_stats()["keys_kept_from"] != 0
+    st.close()

@@ -493,6 +493,24 @@ static hipError_t next_scan_epoch(trag_store* s, bool allowed, hipStream_t st) {
     return err;
 }
 
+// Whether a single-query search on this handle takes the multi-level select, decided per call from what
+// the handle has learned (s->full_select) and from the store as it is now -- so the plan follows a store
+// that grows, and both device entries (with and without allocations) decide alike.
+// Euclidean stores too short for sparse key stores go straight to the multi-level select. Distances
+// between normalised embeddings without near neighbours lie within a few per cent of one another:
+// nearly every row shares the coarse bin (sign, exponent, two mantissa bits) of the k-th best, the
+// one-workgroup select gives up, and a caller of the device entry points, who enqueues far ahead,
+// would see that status on every query enqueued before the handle had learned it. The multi-level
+// form costs 8 us a query more (10 k rows: 41 against 33 us; 1 M: 0.256 against 0.253 ms); on
+// longer scans it would also cost the sparse key stores (10 M x 384: 2.33 against 2.23 ms), so
+// those start with the one-workgroup form, which falls through to the multi-level stages inside the
+// same enqueue when its bin is crowded (see enqueue_search).
+bool plan_full_select(const trag_store* s) {
+    if (s->full_select) return true;
+    return s->cfg.metric == TRAG_EUCLIDEAN && !sparse_scan_pays((uint32_t)((s->n_rows + 63) / 64), 1024u) &&
+           !getenv("TRAG_EUCLID_ONE_WG");
+}
+
 trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_queries, uint32_t k,
                            uint32_t mode, uint32_t* d_out_rows, float* d_out_scores,
                            uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
@@ -508,17 +526,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         const uint32_t ev = *static_cast<volatile uint32_t*>(s->h_events);
         if (ev >= 4 && (uint64_t)ev * 2 >= s->one_wg_queries) s->full_select = true;
     }
-    // Euclidean stores too short for sparse key stores go straight to the multi-level select. Distances
-    // between normalised embeddings without near neighbours lie within a few per cent of one another:
-    // nearly every row shares the coarse bin (sign, exponent, two mantissa bits) of the k-th best, the
-    // one-workgroup select gives up, and a caller of the device entry points, who enqueues far ahead,
-    // would see that status on every query enqueued before the handle had learned it. The multi-level
-    // form costs 8 us a query more (10 k rows: 41 against 33 us; 1 M: 0.256 against 0.253 ms); on
-    // longer scans it would also cost the sparse key stores (10 M x 384: 2.33 against 2.23 ms), so
-    // those still start with the one-workgroup form and learn.
-    if (!s->full_select && s->cfg.metric == TRAG_EUCLIDEAN &&
-        !sparse_scan_pays((uint32_t)((s->n_rows + 63) / 64), 1024u) && !getenv("TRAG_EUCLID_ONE_WG"))
-        s->full_select = true;
+    const bool full_select = plan_full_select(s);
     s->scratch.epoch = 0;  // sparse key stores: only the single-query scans below switch them on
     if (k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP) {
         // More results than the one-workgroup sort holds: exact scan, then a
@@ -592,7 +600,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         if (!s->d_mirror) return fail(TRAG_INVALID_CONFIG, "the bf16 mirror is not enabled on this store");
         // one-workgroup form: some slack below the k-th key so that the coarse cut clears it;
         // multi-level form: the k-th approximate key itself is resolved, then lowered by the bound
-        const uint32_t need_m = s->full_select ? k_eff
+        const uint32_t need_m = full_select ? k_eff
                                                : (uint32_t)std::min<uint64_t>((uint64_t)k_eff + STREAM_SLACK, live);
         ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
         for (uint32_t b = 0; b < n_queries; ++b) {
@@ -600,16 +608,16 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             hipEvent_t e1 = nullptr;
             HIP_TRY(scan_timer_begin(s, st, &e1));
             uint32_t n_waves = 0;
-            HIP_TRY(next_scan_epoch(s, !s->full_select, st));
+            HIP_TRY(next_scan_epoch(s, !full_select, st));
             HIP_TRY(launch_scan_mirror(s->d_mirror, q, s->d_norm2, a, s->scratch, need_m, k_eff, s->d_vmax_sq,
                                        &n_waves, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
-            if (!s->full_select) s->one_wg_queries += 1;
-            HIP_TRY(launch_select_mirror(q, a, s->scratch, s->full_select, live, need_m, k_eff, n_waves,
+            if (!full_select) s->one_wg_queries += 1;
+            HIP_TRY(launch_select_mirror(q, a, s->scratch, full_select, live, need_m, k_eff, n_waves,
                                          d_out_rows + (size_t)b * k, d_out_scores + (size_t)b * k, d_out_n + b,
                                          d_status ? d_status + b : nullptr, st));
             // (the one-workgroup prune clears the coarse histogram itself)
-            if (s->full_select) HIP_TRY(hipMemsetAsync(s->scratch.hist, 0, s->zero_bytes - 256, st));
+            if (full_select) HIP_TRY(hipMemsetAsync(s->scratch.hist, 0, s->zero_bytes - 256, st));
         }
         s->last_ctl = s->scratch.ctl;
         s->stats.mode_used = mode;
@@ -625,7 +633,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
     // Small batches on the exact path: up to MULTI_QUERIES queries share one corpus pass.
     const uint32_t multi_max = multi_group_limit(s->cfg.dim);
-    const bool multi_ok = !rescore && !s->full_select && multi_max >= 2 && n_queries >= 2;
+    const bool multi_ok = !rescore && !full_select && multi_max >= 2 && n_queries >= 2;
     if (multi_ok) {
         ts = ensure_multi_scratch(s);
         if (ts != TRAG_OK) return ts;
@@ -650,14 +658,14 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             continue;
         }
         s->last_ctl = s->scratch.ctl;
-        HIP_TRY(next_scan_epoch(s, !rescore && !s->full_select, st));
+        HIP_TRY(next_scan_epoch(s, !rescore && !full_select, st));
         if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
         else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
         if (e1) HIP_TRY(hipEventRecord(e1, st));
         uint32_t* o_rows = d_out_rows + (size_t)b * k;
         float* o_scores = d_out_scores + (size_t)b * k;
         uint32_t* o_status = d_status ? d_status + b : nullptr;
-        if (!s->full_select) {
+        if (!full_select) {
             s->one_wg_queries += 1;
             HIP_TRY(launch_select_final(q, a, s->scratch, rescore, live, need, k_eff, n_waves, o_rows,
                                         o_scores, d_out_n + b, o_status, st));
@@ -709,7 +717,6 @@ namespace {
 struct NoAllocDevice {
     uint32_t* base = nullptr;
     hipError_t lookup = hipErrorNotInitialized;
-    uint32_t epoch = 0;
 };
 constexpr int NOALLOC_MAX_DEVICES = 64;
 NoAllocDevice g_noalloc[NOALLOC_MAX_DEVICES];
@@ -750,9 +757,8 @@ trag_status trag_store_search_device_noalloc(trag_store* s, const float* d_queri
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
     hipStream_t st = (hipStream_t)hip_stream;
-    if (k == 0 || s->n_live == 0) {
-        HIP_TRY(hipMemsetAsync(d_out_n, 0, n_queries * sizeof(uint32_t), st));
-        if (d_status) HIP_TRY(hipMemsetAsync(d_status, 0, n_queries * sizeof(uint32_t), st));
+    if (k == 0 || s->n_live == 0) {   // (a kernel, as every write of this entry: see launch_zero_words)
+        HIP_TRY(launch_zero_words(d_out_n, n_queries, d_status, d_status ? n_queries : 0u, st));
         return TRAG_OK;
     }
     if (s->n_rows > NOALLOC_MAX_ROWS)
@@ -765,7 +771,7 @@ trag_status trag_store_search_device_noalloc(trag_store* s, const float* d_queri
                                       " needs the global sort's buffer (use trag_store_search_device)");
     trag_status ts = noalloc_setup(s->device);   // (a lookup only, and only if create could not do it)
     if (ts != TRAG_OK) return ts;
-    std::lock_guard<std::mutex> lk2(g_noalloc_mu);   // one enqueue at a time per process: the tag counter
+    std::lock_guard<std::mutex> lk2(g_noalloc_mu);   // one enqueue at a time per process
     NoAllocDevice& nd = g_noalloc[s->device];
     Scratch sc{};
     sc.ctl = reinterpret_cast<SearchCtl*>(nd.base);
@@ -777,41 +783,52 @@ trag_status trag_store_search_device_noalloc(trag_store* s, const float* d_queri
     sc.tmax = nd.base + NA_TMAX;
     sc.keys = nd.base + NA_KEYS;
     sc.events = nullptr;   // no pinned word here: this entry follows the plan the handle has, it learns none
-    ts = finish_inserts(s);   // (kernel launches only)
-    if (ts == TRAG_OK) ts = order_after_last(s, st);
-    if (ts != TRAG_OK) return ts;
-    // the array keeps what the last call left, possibly of another store or of a call that failed
-    // half way: the accumulators start from zero (keys, tile and wave maxima are rewritten by every
-    // scan for every row they are read for; the published wave bests are told apart by their tag)
-    HIP_TRY(hipMemsetAsync(nd.base, 0, NA_ZERO_WORDS * sizeof(uint32_t), st));
+    // Under stream capture the call is recorded, not run: work on other streams cannot be ordered
+    // against it here (the handle's own stream is not part of the capture), and nothing the handle
+    // remembers about its last call describes the replays. Rows appended by small inserts must have
+    // been brought up to date by an earlier search; the caller orders replays against the handle's
+    // other calls.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap == hipStreamCaptureStatusActive) {
+        if (s->dirty_from < s->n_rows)
+            return fail(TRAG_UNSUPPORTED, "rows were inserted since the last search: run one search outside the capture first");
+    } else {
+        ts = finish_inserts(s);   // (kernel launches only)
+        if (ts == TRAG_OK) ts = order_after_last(s, st);
+        if (ts != TRAG_OK) return ts;
+    }
+    // The array keeps what the last call left, possibly of another store, of a call that failed half
+    // way, or -- a captured call replayed -- of this very call: the accumulators and the published wave
+    // bests start from zero in every call (keys, tile and wave maxima are rewritten by every scan for
+    // every row they are read for). The tag that tells the bests of one scan from another's is the
+    // query's number inside the call: a tag that survived the call would be baked into a captured graph
+    // and every replay would take the previous replay's bests for its own.
     if (s->sparse_keys < 0) {
         const char* e = getenv("TRAG_SPARSE_KEYS");
         s->sparse_keys = (e && e[0] == '0') ? 0 : 1;
     }
+    const bool full_select = plan_full_select(s);
+    const bool sparse = s->sparse_keys && !full_select;
+    HIP_TRY(launch_zero_words(nd.base, (uint32_t)NA_ZERO_WORDS, reinterpret_cast<uint32_t*>(sc.wbest),
+                              sparse ? 2u * SPARSE_WAVES : 0u, st));
     const size_t hist_bytes = (size_t)HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
     ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
     for (uint32_t b = 0; b < n_queries; ++b) {
         const float* q = d_queries + (size_t)b * dim;
-        sc.epoch = 0;
-        if (s->sparse_keys && !s->full_select) {
-            if (++nd.epoch == 0u) {
-                nd.epoch = 1;
-                HIP_TRY(hipMemsetAsync(sc.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st));
-            }
-            sc.epoch = nd.epoch;
-        }
+        sc.epoch = sparse ? b + 1u : 0u;
         uint32_t n_waves = 0;
         HIP_TRY(launch_scan_exact(q, a, sc, k_eff, k_eff, s->d_vmax_sq, &n_waves, st));
         uint32_t* o_rows = d_out_rows + (size_t)b * k;
         float* o_scores = d_out_scores + (size_t)b * k;
         uint32_t* o_status = d_status ? d_status + b : nullptr;
-        if (!s->full_select) {
+        if (!full_select) {
             HIP_TRY(launch_select_final(q, a, sc, false, live, k_eff, k_eff, n_waves, o_rows, o_scores,
                                         d_out_n + b, o_status, st));
         } else {
             HIP_TRY(launch_select(a, sc, st));
             HIP_TRY(launch_final(q, a, sc, false, live, o_rows, o_scores, d_out_n + b, o_status, st));
-            HIP_TRY(hipMemsetAsync(sc.hist, 0, hist_bytes, st));
+            HIP_TRY(launch_zero_words(sc.hist, (uint32_t)(hist_bytes / sizeof(uint32_t)), nullptr, 0u, st));
             HIP_TRY(launch_reset_ctl(sc, st));
         }
     }

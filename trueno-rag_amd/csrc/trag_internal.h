@@ -242,6 +242,7 @@ hipError_t launch_pack_topk(const uint32_t* d_rows, const float* d_scores, const
 hipError_t launch_merge_packed(const uint32_t* d_gathered, uint32_t n_lists, uint32_t n_queries,
                                uint32_t k, uint32_t* d_out_rows, float* d_out_scores,
                                uint32_t* d_out_n, hipStream_t st, uint32_t* d_out_status = nullptr);
+hipError_t launch_zero_words(uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb, hipStream_t st);
 hipError_t launch_stream_probe(const float* d_rows, uint64_t n_floats, float* d_sink, hipStream_t st);
 hipError_t launch_update_vmax(const float* d_rows, uint64_t n, uint32_t dim, float* d_vmax_sq,
                               float* d_norm2_out, hipStream_t st);

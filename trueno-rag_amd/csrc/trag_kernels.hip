@@ -1075,14 +1075,22 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     find_bin<1024>(hist, need, b1, above1, sh, &inbin1);
     const uint32_t expect = above1 + inbin1;
     uint32_t status = ST_OK, n_out = 0, C = 0;
-    if (expect > CAND_CAP) {
+    // A crowded coarse bin (clustered scores: Euclidean distances between normalised vectors, big tie
+    // groups) holds more rows than the sort. When the scan ran with sparse key stores its bound does
+    // the cutting instead: `need` rows reach keep_sh, the rows at or above it are few (about
+    // need x rows / rows seen before the waves' last publication) and every one of them has its key
+    // stored -- the crowd below is never looked at. Only when that set overflows as well (a tie group
+    // of thousands of rows at the very top) is the multi-level form asked for.
+    const bool crowded = expect > CAND_CAP;
+    const bool by_bound = crowded && keep_sh > (b1 << 21);   // (find_bin's barriers ordered keep_sh)
+    if (crowded && !by_bound) {
         status = ST_NEED_REFINE;
     } else {
         if (tid == 0) { n_hit_sh = 0; n_cand_sh = 0; n_thit_sh = 0; }
-        __syncthreads();  // (find_bin's barriers already ordered keep_sh)
+        __syncthreads();
         const uint32_t t_key = max(b1 << 21, keep_sh);
         const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
-        if (expect <= CAND_CAP / 2) {
+        if (expect <= CAND_CAP / 2 || by_bound) {
             gather_flat(t_min, 0xFFFFFFFFu, RESCORE, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit,
                         &n_hit_sh, &n_thit_sh, &n_cand_sh);
         } else {
@@ -1127,8 +1135,12 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         }
         C = n_cand_sh < CAND_CAP ? n_cand_sh : CAND_CAP;
         n_out = k < C ? k : C;
+        // (cut by the bound: the flat gather holds CAND_CAP / 2 rows, CAND_CAP waves and tiles)
+        const bool overflow = by_bound && (n_cand_sh > CAND_CAP / 2 || n_hit_sh > CAND_CAP || n_thit_sh > CAND_CAP);
+        if (overflow) { status = ST_NEED_REFINE; C = 0; n_out = 0; }
         float ek = 0.0f;  // score of the last returned row (thread 0)
-        if (C <= 64u) {
+        if (overflow) {
+        } else if (C <= 64u) {
             // the usual case: one wave sorts its candidates in registers
             if (wid == 0) {
                 unsigned long long v = 0ull;
@@ -1824,6 +1836,22 @@ stream_probe_kernel(const v4f* __restrict__ p, unsigned long long n4, float* __r
         for (int u = 0; u < 8; ++u) acc += x[u];
     }
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[0] = acc.x;  // keeps the loads alive
+}
+
+// Zeroes two word ranges in one launch (the no-allocation entry's accumulators and published wave
+// bests: a kernel, not hipMemsetAsync -- captured into a HIP graph, a memset node in front of the
+// scan was seen to run unordered with it on every replay after the first).
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* __restrict__ a, uint32_t na, uint32_t* __restrict__ b, uint32_t nb) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < na) a[i] = 0u;
+    else if (i - na < nb) b[i - na] = 0u;
+}
+
+hipError_t launch_zero_words(uint32_t* a, uint32_t na, uint32_t* b, uint32_t nb, hipStream_t st) {
+    const uint32_t n = na + nb;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a, na, b, nb);
+    return hipGetLastError();
 }
 
 hipError_t launch_stream_probe(const float* d_rows, uint64_t n_floats, float* d_sink, hipStream_t st) {
