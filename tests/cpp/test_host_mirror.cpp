@@ -159,6 +159,21 @@ int main() {
         auto res = hr.retrieve("beta decay", 3);
         EXPECT(res.size() == 3 && res[0].chunk.id == cs[1].id && res[0].sparse_score.has_value());
     }
+    {   // SparseRetriever: src/retrieve.rs:300-335, the reference's unit tests :568-658
+        SparseRetriever<> empty;
+        EXPECT(empty.retrieve("test", 10).empty());
+        SparseRetriever<> one;
+        one.index(Chunk("machine learning test"));
+        auto r1 = one.retrieve("machine", 10);
+        EXPECT(r1.size() == 1 && r1[0].sparse_score.has_value() && !r1[0].dense_score.has_value());
+        auto two = SparseRetriever<BM25Index>::with_index(BM25Index::with_params(1.5f, 0.5f));
+        Chunk a("rust programming language"), b("python programming language");
+        const ChunkId ia = a.id;
+        two.index(a);
+        two.index(b);
+        EXPECT(two.retrieve("programming", 10).size() == 2);
+        EXPECT(two.retrieve("programming", 1)[0].chunk.id == ia);   // equal scores: insertion order
+    }
     {   // insert_batch: one call for the new rows; a known id is overwritten, a repeated id keeps its last row
         VectorStore s = VectorStore::with_dimension(2);
         Chunk old = chunk_with("old", {1.0f, 0.0f});

@@ -243,3 +243,21 @@ def test_reference_bench_shape(trag):
         assert len(res) == k
         assert [chunks[int(d)].id for d in od] == [r[0] for r in res]
         assert np.asarray([r[1] for r in res], dtype=np.float32).tobytes() == os_.tobytes()
+
+
+def test_sparse_retriever_reference_unit_tests(trag):
+    """SparseRetriever, src/retrieve.rs:300-335, with the reference's own unit tests (:568-658) over the
+    GPU-resident BM25 index."""
+    r = trag.SparseRetriever.new()
+    assert r.retrieve("test", 10) == []                                   # test_sparse_retriever_new / _default
+    r.index(trag.Chunk("machine learning test"))
+    res = r.retrieve("machine", 10)
+    assert len(res) == 1 and res[0].sparse_score is not None              # test_sparse_retriever_index
+    assert res[0].dense_score is None and res[0].best_score() == res[0].sparse_score
+    m = trag.SparseRetriever.with_index(trag.BM25Index.with_params(1.5, 0.5))
+    a, b = trag.Chunk("rust programming language"), trag.Chunk("python programming language")
+    m.index(a)
+    m.index(b)
+    res = m.retrieve("programming", 10)
+    assert len(res) == 2 and {x.chunk.id for x in res} == {a.id, b.id}    # test_sparse_retriever_multiple
+    assert m.retrieve("programming", 1)[0].chunk.id == a.id               # equal scores: insertion order

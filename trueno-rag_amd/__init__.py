@@ -16,8 +16,8 @@ from .persist import PersistedIndex, PersistedChunk, IndexServer  # noqa: F401
 from .fusion import FusionStrategy  # noqa: F401
 from .rerank import LexicalReranker, NoOpReranker  # noqa: F401
 from .retrieve import (DenseRetriever, HybridRetriever, HybridRetrieverConfig,  # noqa: F401
-                       RetrievalResult)
+                       RetrievalResult, SparseRetriever)
 
 __all__ = ["lib", "lib_path", "TragError", "DimensionMismatch", "InvalidConfig", "VectorStore",
            "VectorStoreConfig", "DistanceMetric", "ScanMode", "Chunk", "ChunkId", "BM25Index", "MockEmbedder", "EmbeddingConfig", "EmptyDocument", "QueryError", "PersistedIndex", "PersistedChunk", "IndexServer", "FusionStrategy",
-           "LexicalReranker", "NoOpReranker", "DenseRetriever", "HybridRetriever", "HybridRetrieverConfig", "RetrievalResult"]
+           "LexicalReranker", "NoOpReranker", "DenseRetriever", "HybridRetriever", "HybridRetrieverConfig", "RetrievalResult", "SparseRetriever"]

@@ -455,4 +455,30 @@ class DenseRetriever {  // :266-297
     E embedder_;
 };
 
+// src/retrieve.rs:300-335: sparse-only retrieval over any SparseIndex S (add, search); the chunks are kept
+// here, keyed by id, as the reference keeps them.
+template <class S = BM25Index>
+class SparseRetriever {
+  public:
+    SparseRetriever() = default;
+    explicit SparseRetriever(S index) : index_(std::move(index)) {}
+    static SparseRetriever with_index(S index) { return SparseRetriever(std::move(index)); }
+    void index(Chunk chunk) {  // :316-319
+        index_.add(chunk);
+        const ChunkId id = chunk.id;
+        chunks_.insert_or_assign(id, std::move(chunk));
+    }
+    std::vector<RetrievalResult> retrieve(const std::string& query, size_t k) {  // :323-334
+        std::vector<RetrievalResult> out;
+        for (auto& p : index_.search(query, k))
+            if (auto it = chunks_.find(p.first); it != chunks_.end())
+                out.push_back(RetrievalResult{it->second, {}, p.second, {}, {}});
+        return out;
+    }
+
+  private:
+    S index_{};
+    std::unordered_map<ChunkId, Chunk, ChunkIdHash> chunks_;
+};
+
 }  // namespace trueno_rag

@@ -154,3 +154,36 @@ class DenseRetriever:
             if chunk is not None:
                 out.append(RetrievalResult(chunk).with_dense_score(score))
         return out
+
+
+class SparseRetriever:
+    """src/retrieve.rs:300-335: sparse-only retrieval. `index` is any SparseIndex (add(chunk),
+    search(query, k) -> [(ChunkId, score)]); by default the GPU-resident BM25Index. The chunks are kept
+    here, keyed by id, as the reference keeps them."""
+
+    def __init__(self, index=None):
+        if index is None:
+            from .sparse import BM25Index
+            index = BM25Index.new()
+        self._index = index
+        self.chunks = {}
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    @classmethod
+    def with_index(cls, index):
+        return cls(index)
+
+    def index(self, chunk: Chunk) -> None:
+        self._index.add(chunk)                 # src/retrieve.rs:317
+        self.chunks[chunk.id] = chunk          # :318
+
+    def retrieve(self, query: str, k: int) -> List[RetrievalResult]:
+        out = []
+        for chunk_id, score in self._index.search(query, k):
+            chunk = self.chunks.get(chunk_id)  # ids without a chunk are dropped (:329-331)
+            if chunk is not None:
+                out.append(RetrievalResult(chunk).with_sparse_score(score))
+        return out

@@ -320,7 +320,9 @@ impl DenseIndex for GpuShardedVectorStore {
 }
 
 // ---------------------------------------------------------------------------
-// BM25: `impl SparseIndex for GpuBm25Index` (src/index.rs:8-28, 175-280).
+// BM25: `impl SparseIndex for GpuBm25Index` (src/index.rs:8-28, 175-280). With the patched crate it
+// serves every holder of a sparse index: `HybridRetriever::new(dense, GpuBm25Index::new(), embedder)` and
+// `SparseRetriever::with_index(GpuBm25Index::new())` (src/retrieve.rs:300-335).
 // The tokenizer is the reference's own (`BM25Index::tokenize`, a pub fn,
 // src/index.rs:111-124): a default `BM25Index` is kept only to call it.
 // ---------------------------------------------------------------------------
