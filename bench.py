@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--host", action="store_true",
                     help="time the host-pointer entry (trag_store_search: query from host memory, results to host "
                          "memory, synchronous) instead of the device-resident one; the shape of the smallest benchmark configuration (10 000 x 384)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="single-query steps: keep the select on the stream of the scans (by default the handle is in "
+                         "pipelined mode: the select of query i runs beside the scan of query i+1, results fenced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 counter pass that measures the scan kernel's HBM traffic")
@@ -140,6 +143,9 @@ def main():
     store.fill_synthetic(n_local, seed, first_global_row=row0)
     if args.mirror:
         store.set_bf16_mirror(True)
+    pipelined = not args.no_pipeline and args.batch == 1 and not args.host and not args.hybrid
+    if pipelined:   # (a sharded run's exchange group switches it on itself: overlap mode)
+        store.set_pipelined(True)
 
     B = args.batch
     n_q = (args.steps + args.warmup) * B
@@ -242,6 +248,7 @@ def main():
                             m_rows[i:i + B], m_scores[i:i + B], m_n[i:i + B], side.cuda_stream)
 
     def fence():
+        store.fence(sptr)          # pipelined handle: the selects on its side stream
         if group is not None:
             group.fence(sptr)
         torch.cuda.synchronize()
@@ -435,6 +442,8 @@ def main():
                        "bf16_mirror": bool(args.mirror),
                        "entry": "host pointers (PCIe + synchronisation inside every step)" if args.host
                                 else "device-resident queries and results",
+                       "pipelined": ("select of query i on the handle's side stream beside the scan of query i+1; "
+                                     "all results fenced inside the timed region") if pipelined else None,
                        "latency_us_per_call": 1e3 * ms_per_step if args.host else None,
                        "path_used": {1: "exact scan (f32, reference order)", 2: "streaming scan + exact re-score",
                                      3: "f32 matrix cores + exact re-score",

@@ -28,6 +28,8 @@
  *    stream, then the handle's own, or two caller streams) first makes the new
  *    stream wait for the work the previous call enqueued. A stream passed to a
  *    `_device` entry must stay alive until the handle's next call.
+ *    (A handle in pipelined mode, trag_store_set_pipelined, holds two scratch sets and overlaps the
+ *    select of one single-query search with the scan of the next; see there.)
  */
 #ifndef TRAG_H
 #define TRAG_H
@@ -152,6 +154,22 @@ trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint
                                      float *d_out_scores, uint32_t *d_out_n,
                                      uint32_t *d_status, void *hip_stream);
 
+/* Pipelined single-query searches on the device entry. VectorStore::search (src/index.rs:386-412) is
+ * "score every row, then order": on the GPU a scan of the corpus and a one-workgroup select behind
+ * it, which runs alone on the device (17 us behind a 235 us scan of 1 M x 384). With pipelining
+ * enabled a handle keeps two search scratch sets and its own side stream: the scan of a query runs
+ * on the caller's stream, its select on the side stream beside the NEXT query's scan. Only
+ * trag_store_search_device calls with one query that take the exact-order scan and the
+ * one-workgroup select are pipelined; every other route first waits for the pipeline and then runs
+ * on the caller's stream as before. The outputs of a pipelined call (rows, scores, count, status) are
+ * written on the side stream: a stream may read them only after trag_store_fence on it. Host-pointer
+ * entries are unaffected (they wait for their own results). Costs a second scratch set (8 bytes per
+ * row instead of 4). No counterpart in the reference. */
+trag_status trag_store_set_pipelined(trag_store *s, int enabled);
+/* Makes hip_stream wait for every select the handle has enqueued on its side stream so far (a no-op
+ * on a handle that is not pipelined). Enqueues a wait, does not block the host. */
+trag_status trag_store_fence(trag_store *s, void *hip_stream);
+
 /* No counterpart in the reference. For callers that cannot allocate device memory -- code
  * under HIP graph capture, serving loops with a frozen memory plan, harnesses that forbid
  * hipMalloc: trag_store_search_device for single-query exact scans with the search scratch
@@ -271,8 +289,10 @@ typedef struct trag_shard_config {
     uint32_t max_queries; /* largest batch of one trag_shard_search_device call */
     uint32_t overlap;     /* 0: pack, all-gather and merge follow the local search on the caller's
                              stream. 1: they run on the group's own stream, so the next call's scan
-                             overlaps this call's exchange; results are visible to a stream only
-                             after trag_shard_fence on it. */
+                             overlaps this call's exchange -- and the local store is switched to
+                             pipelined mode (trag_store_set_pipelined), so the select of a
+                             single-query step leaves the scans' stream as well; results are
+                             visible to a stream only after trag_shard_fence on it. */
 } trag_shard_config;
 trag_status trag_shard_unique_id(uint8_t *id /* TRAG_SHARD_ID_BYTES */);
 trag_status trag_shard_group_create(const trag_shard_config *cfg, const uint8_t *id, trag_shard_group **out);

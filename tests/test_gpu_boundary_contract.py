@@ -181,3 +181,95 @@ def test_clone_is_an_independent_copy(trag, oracle):
     assert rows[0] == n and rows[1] == er[1]
     rows, scores = store.search_rows(q, 10)      # the source never saw any of that
     assert np.array_equal(rows, er) and store.len() == n - 3 and twin.len() == n - 3
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metric):
+    """Pipelined mode (trag_store_set_pipelined): the select of query i runs on the handle's side stream
+    beside the scan of query i + 1. 40 single-query searches enqueued back to back on a user stream,
+    a host-entry search and a batch in between (other routes: they wait for the pipeline), a second
+    user stream; outputs are read only after trag_store_fence -- all equal the oracle's."""
+    import torch
+    n, d, k, B = 1_500_000, 64, 10, 40
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(metric), device=0,
+                                                    reserve_rows=n))
+    store.fill_synthetic(n, 171)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(172, 0, B, d)
+    dq = torch.from_numpy(Q).cuda()
+    rows = torch.zeros((B, k), dtype=torch.int32, device="cuda")
+    scores = torch.zeros((B, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    status = torch.full((B,), 9, dtype=torch.int32, device="cuda")
+    user, other = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    store.set_pipelined(True)
+    host = {}
+    for b in range(B):
+        st = other if b in (17, 18) else user          # a change of stream in the middle of the run
+        store.search_device(dq.data_ptr() + b * d * 4, 1, k, rows.data_ptr() + b * k * 4, scores.data_ptr() + b * k * 4,
+                            cnt.data_ptr() + b * 4, status.data_ptr() + b * 4, st.cuda_stream)
+        if b == 9:
+            host[9] = store.search_rows(Q[9], k)        # host entry: not pipelined, waits for the pipeline
+        if b == 25:
+            host["batch"] = store.search_batch_rows(Q[:12], k)
+    # results may be read on a stream only behind the fence
+    store.fence(user.cuda_stream)
+    out = torch.empty_like(rows)
+    with torch.cuda.stream(user):
+        out.copy_(rows)
+    user.synchronize()
+    other.synchronize()
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0] * B and cnt.cpu().tolist() == [k] * B
+    assert torch.equal(out.cpu()[:17], rows.cpu()[:17]) and torch.equal(out.cpu()[19:], rows.cpu()[19:])
+    want = [oracle.search(corpus, Q[b], k, metric) for b in range(B)]
+    for b in range(B):
+        assert_same_ranking(rows[b].cpu().numpy().astype(np.uint32), scores[b].cpu().numpy(), want[b][0], want[b][1],
+                            f"pipelined query {b}")
+    assert_same_ranking(host[9][0], host[9][1], want[9][0], want[9][1], "host entry inside the pipeline")
+    for b in range(12):
+        assert_same_ranking(host["batch"][0][b], host["batch"][1][b], want[b][0], want[b][1], f"batch query {b}")
+    # switched off again: single-stream behaviour, no fence needed
+    store.set_pipelined(False)
+    rows.zero_()
+    store.search_device(dq.data_ptr(), 1, k, rows.data_ptr(), scores.data_ptr(), cnt.data_ptr(), status.data_ptr(),
+                        user.cuda_stream)
+    user.synchronize()
+    assert_same_ranking(rows[0].cpu().numpy().astype(np.uint32), scores[0].cpu().numpy(), want[0][0], want[0][1], "off")
+    store.close()
+
+
+def test_pipelined_outputs_are_not_ordered_on_the_callers_stream_without_the_fence(trag, oracle):
+    """What the fence is for: in pipelined mode the select writes the outputs on the handle's side stream,
+    so a copy enqueued on the caller's stream right behind the call -- no fence -- is not ordered behind
+    it and can read the outputs before they are written (it runs as soon as the scan has finished, beside
+    the select). The same copy behind trag_store_fence always sees them."""
+    import torch
+    n, d, k = 3_000_000, 64, 10
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0, reserve_rows=n))
+    store.fill_synthetic(n, 173)
+    q = oracle.synth_rows(174, 0, 1, d)
+    dq = torch.from_numpy(q).cuda()
+    want_rows, _ = store.search_rows(q[0], k)
+    store.set_pipelined(True)
+    user = torch.cuda.Stream()
+    stale_seen, fenced_ok = 0, 0
+    for rep in range(8):
+        rows = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+        scores = torch.zeros(k, dtype=torch.float32, device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        early, late = torch.zeros_like(rows), torch.zeros_like(rows)
+        torch.cuda.synchronize()
+        store.search_device(dq.data_ptr(), 1, k, rows.data_ptr(), scores.data_ptr(), cnt.data_ptr(), 0, user.cuda_stream)
+        with torch.cuda.stream(user):
+            early.copy_(rows)                  # no fence: only ordered behind the scan
+        store.fence(user.cuda_stream)
+        with torch.cuda.stream(user):
+            late.copy_(rows)                   # behind the fence: ordered behind the select
+        user.synchronize()
+        stale_seen += int(early.cpu().tolist() != want_rows.astype(np.int32).tolist())
+        fenced_ok += int(late.cpu().tolist() == want_rows.astype(np.int32).tolist())
+    assert fenced_ok == 8
+    assert stale_seen >= 1, "the unfenced copy was never early: is the select still on the caller's stream?"
+    store.close()

@@ -73,6 +73,8 @@ SIGNATURES = {
     "trag_store_search_batch": (C.c_int, [_H, _fp, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _fp, _u32p]),
     "trag_store_search_device": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "trag_store_set_pipelined": (C.c_int, [_H, C.c_int]),
+    "trag_store_fence": (C.c_int, [_H, C.c_void_p]),
     "trag_store_search_device_noalloc": (C.c_int, [_H, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32,
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "trag_store_fill_synthetic": (C.c_int, [_H, C.c_uint64, C.c_uint64, C.c_uint64, _u32p]),

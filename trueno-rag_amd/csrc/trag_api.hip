@@ -120,6 +120,17 @@ struct trag_store {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     hipEvent_t order_ev = nullptr;
+    // Pipelined single-query searches (trag_store_set_pipelined): two scratch sets alternate, the scan
+    // of a query runs on the caller's stream and its one-workgroup select on `side`, beside the next
+    // query's scan; sel_done[x] marks the end of the last select that used set x.
+    bool pipelined = false;
+    Scratch scratch2{};
+    void* zero_block2 = nullptr;
+    uint64_t keys_cap2 = 0;
+    hipStream_t side = nullptr;
+    hipEvent_t scan_done[2] = {nullptr, nullptr}, sel_done[2] = {nullptr, nullptr};
+    bool pipe_used[2] = {false, false};
+    uint32_t pipe_next = 0;
     std::mutex mu;
     trag_search_stats stats{};
     // optional scan timing
@@ -187,6 +198,7 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
         if (nmirror) (void)hipFree(nmirror);
         return fail(TRAG_DEVICE_ERROR, std::string("growing the store: ") + hipGetErrorString(e));
     }
+    if (s->side) (void)hipStreamSynchronize(s->side);
     if (s->d_rows) (void)hipFree(s->d_rows);
     if (s->d_dead) (void)hipFree(s->d_dead);
     if (s->d_norm2) (void)hipFree(s->d_norm2);
@@ -200,46 +212,68 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
     return TRAG_OK;
 }
 
-trag_status ensure_scratch(trag_store* s) {
-    if (!s->scratch.cand) HIP_TRY(hipMalloc(&s->scratch.cand, CAND_CAP * sizeof(uint32_t)));
-    if (!s->scratch.ckeys) HIP_TRY(hipMalloc(&s->scratch.ckeys, CAND_CAP * sizeof(uint32_t)));
+// One search scratch set (the handle has one; a pipelined handle two). A set that must grow is only
+// replaced once nothing can still be using it: the caller has drained the pipeline.
+trag_status ensure_scratch_set(trag_store* s, Scratch& sc, void*& zero_block, uint64_t& keys_cap) {
+    if (!sc.cand) HIP_TRY(hipMalloc(&sc.cand, CAND_CAP * sizeof(uint32_t)));
+    if (!sc.ckeys) HIP_TRY(hipMalloc(&sc.ckeys, CAND_CAP * sizeof(uint32_t)));
     if (!s->h_events) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_events), 64, hipHostMallocMapped));
         *s->h_events = 0u;
+    }
+    if (!sc.events) {
         void* dp = nullptr;
         HIP_TRY(hipHostGetDevicePointer(&dp, s->h_events, 0));
-        s->scratch.events = static_cast<uint32_t*>(dp);
+        sc.events = static_cast<uint32_t*>(dp);
     }
-    if (s->keys_cap < s->cap_rows || !s->zero_block) {
-        void* old[] = {s->scratch.keys, s->scratch.tmax, s->zero_block};
+    if (keys_cap < s->cap_rows || !zero_block) {
+        void* old[] = {sc.keys, sc.tmax, zero_block};
         for (void* p : old)
             if (p) (void)hipFree(p);
-        s->scratch.keys = nullptr;
-        s->scratch.tmax = nullptr;
-        s->zero_block = nullptr;
-        s->keys_cap = 0;
+        sc.keys = nullptr;
+        sc.tmax = nullptr;
+        zero_block = nullptr;
+        keys_cap = 0;
         s->last_ctl = nullptr;
         const size_t ctl_bytes = 256;  // SearchCtl padded
         static_assert(sizeof(SearchCtl) <= 256, "control block grew");
         s->zero_bytes = ctl_bytes + HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
-        HIP_TRY(hipMalloc(&s->zero_block, s->zero_bytes));
+        HIP_TRY(hipMalloc(&zero_block, s->zero_bytes));
         // stream-ordered clear, finished before any stream can use the block (a plain
         // hipMemset on the null stream is not ordered against non-blocking streams)
-        HIP_TRY(hipMemsetAsync(s->zero_block, 0, s->zero_bytes, s->stream));
+        HIP_TRY(hipMemsetAsync(zero_block, 0, s->zero_bytes, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
-        s->scratch.ctl = reinterpret_cast<SearchCtl*>(s->zero_block);
-        s->scratch.hist = reinterpret_cast<uint32_t*>(static_cast<char*>(s->zero_block) + ctl_bytes);
-        if (!s->scratch.wmax) HIP_TRY(hipMalloc(&s->scratch.wmax, WMAX_CAP * sizeof(uint32_t)));
-        if (!s->scratch.wbest) {
-            HIP_TRY(hipMalloc(&s->scratch.wbest, SPARSE_WAVES * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(s->scratch.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), s->stream));
+        sc.ctl = reinterpret_cast<SearchCtl*>(zero_block);
+        sc.hist = reinterpret_cast<uint32_t*>(static_cast<char*>(zero_block) + ctl_bytes);
+        if (!sc.wmax) HIP_TRY(hipMalloc(&sc.wmax, WMAX_CAP * sizeof(uint32_t)));
+        if (!sc.wbest) {
+            HIP_TRY(hipMalloc(&sc.wbest, SPARSE_WAVES * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(sc.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), s->stream));
             HIP_TRY(hipStreamSynchronize(s->stream));
         }
-        HIP_TRY(hipMalloc(&s->scratch.keys, (size_t)s->cap_rows * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&s->scratch.tmax, ((size_t)s->cap_rows / 64 + 1) * sizeof(uint32_t)));
-        s->keys_cap = s->cap_rows;
+        HIP_TRY(hipMalloc(&sc.keys, (size_t)s->cap_rows * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&sc.tmax, ((size_t)s->cap_rows / 64 + 1) * sizeof(uint32_t)));
+        keys_cap = s->cap_rows;
     }
     return TRAG_OK;
+}
+
+// Makes `st` wait for the selects a pipelined handle has on its side stream (no-op otherwise).
+trag_status drain_pipeline(trag_store* s, hipStream_t st) {
+    for (int x = 0; x < 2; ++x)
+        if (s->pipe_used[x]) HIP_TRY(hipStreamWaitEvent(st, s->sel_done[x], 0));
+    return TRAG_OK;
+}
+
+trag_status ensure_scratch(trag_store* s) {
+    // (a set is replaced when the store has grown: nothing of the pipeline may still be reading it)
+    if ((s->keys_cap < s->cap_rows || (s->pipelined && s->keys_cap2 < s->cap_rows)) && (s->pipe_used[0] || s->pipe_used[1])) {
+        HIP_TRY(hipStreamSynchronize(s->side));
+        s->pipe_used[0] = s->pipe_used[1] = false;
+    }
+    trag_status ts = ensure_scratch_set(s, s->scratch, s->zero_block, s->keys_cap);
+    if (ts == TRAG_OK && s->pipelined) ts = ensure_scratch_set(s, s->scratch2, s->zero_block2, s->keys_cap2);
+    return ts;
 }
 
 trag_status ensure_multi_scratch(trag_store* s) {
@@ -442,6 +476,10 @@ hipError_t scan_timer_begin(trag_store* s, hipStream_t st, hipEvent_t* closing) 
 // must not be destroyed before the handle's next call; if recording on it fails the device is
 // drained instead.)
 trag_status order_after_last(trag_store* s, hipStream_t st) {
+    if (s->has_last && s->last_stream != st) {   // (selects of a pipelined handle run on its side stream)
+        trag_status td = drain_pipeline(s, st);
+        if (td != TRAG_OK) return td;
+    }
     if (s->has_last && s->last_stream != st && s->order_ev) {
         hipError_t e = hipEventRecord(s->order_ev, s->last_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(st, s->order_ev, 0);
@@ -477,19 +515,22 @@ trag_status finish_inserts(trag_store* s) {
 // Tags the next single-query scan for the sparse key stores (the tag tells this scan's
 // wbest[] entries from older ones; 0 = off: the multi-level select reads every key).
 // TRAG_SPARSE_KEYS=0 turns them off for the process.
-static hipError_t next_scan_epoch(trag_store* s, bool allowed, hipStream_t st) {
+static hipError_t next_scan_epoch(trag_store* s, Scratch& sc, bool allowed, hipStream_t st) {
     if (s->sparse_keys < 0) {
         const char* e = getenv("TRAG_SPARSE_KEYS");
         s->sparse_keys = (e && e[0] == '0') ? 0 : 1;
     }
-    s->scratch.epoch = 0;
-    if (!s->sparse_keys || !allowed || !s->scratch.wbest) return hipSuccess;
+    sc.epoch = 0;
+    if (!s->sparse_keys || !allowed || !sc.wbest) return hipSuccess;
     hipError_t err = hipSuccess;
-    if (++s->scan_epoch == 0u) {   // wrapped: forget every old tag
+    if (++s->scan_epoch == 0u) {   // wrapped: forget every old tag (of both scratch sets, nothing in flight)
         s->scan_epoch = 1;
-        err = hipMemsetAsync(s->scratch.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st);
+        if (s->side && (s->pipe_used[0] || s->pipe_used[1])) err = hipStreamSynchronize(s->side);
+        if (err == hipSuccess) err = hipMemsetAsync(s->scratch.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st);
+        if (err == hipSuccess && s->scratch2.wbest)
+            err = hipMemsetAsync(s->scratch2.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st);
     }
-    s->scratch.epoch = s->scan_epoch;
+    sc.epoch = s->scan_epoch;
     return err;
 }
 
@@ -513,7 +554,7 @@ bool plan_full_select(const trag_store* s) {
 
 trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_queries, uint32_t k,
                            uint32_t mode, uint32_t* d_out_rows, float* d_out_scores,
-                           uint32_t* d_out_n, uint32_t* d_status, hipStream_t st) {
+                           uint32_t* d_out_n, uint32_t* d_status, hipStream_t st, bool may_pipeline = false) {
     trag_status ts = ensure_scratch(s);
     if (ts != TRAG_OK) return ts;
     const uint32_t live = (uint32_t)s->n_live;
@@ -528,6 +569,15 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     }
     const bool full_select = plan_full_select(s);
     s->scratch.epoch = 0;  // sparse key stores: only the single-query scans below switch them on
+    // Pipelined form (device entry of a handle that asked for it, one exact-order query, the
+    // one-workgroup select): every other route runs on `st` alone, behind whatever the pipeline still
+    // has on the side stream.
+    const bool pipe = may_pipeline && s->pipelined && s->side && n_queries == 1 && mode == TRAG_SCAN_EXACT &&
+                      !full_select && !(k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP);
+    if (!pipe && (s->pipe_used[0] || s->pipe_used[1])) {
+        ts = drain_pipeline(s, st);
+        if (ts != TRAG_OK) return ts;
+    }
     if (k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP) {
         // More results than the one-workgroup sort holds: exact scan, then a
         // global sort of every row's rank key (rare; the reference's callers ask
@@ -608,7 +658,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             hipEvent_t e1 = nullptr;
             HIP_TRY(scan_timer_begin(s, st, &e1));
             uint32_t n_waves = 0;
-            HIP_TRY(next_scan_epoch(s, !full_select, st));
+            HIP_TRY(next_scan_epoch(s, s->scratch, !full_select, st));
             HIP_TRY(launch_scan_mirror(s->d_mirror, q, s->d_norm2, a, s->scratch, need_m, k_eff, s->d_vmax_sq,
                                        &n_waves, st));
             if (e1) HIP_TRY(hipEventRecord(e1, st));
@@ -657,14 +707,34 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             b += group - 1;
             continue;
         }
-        s->last_ctl = s->scratch.ctl;
-        HIP_TRY(next_scan_epoch(s, !rescore && !full_select, st));
-        if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
-        else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
-        if (e1) HIP_TRY(hipEventRecord(e1, st));
         uint32_t* o_rows = d_out_rows + (size_t)b * k;
         float* o_scores = d_out_scores + (size_t)b * k;
         uint32_t* o_status = d_status ? d_status + b : nullptr;
+        if (pipe) {
+            // scan on the caller's stream, select on the side stream beside the NEXT query's scan; the
+            // set's previous select (two queries ago) must have finished before this scan writes into it
+            const uint32_t x = s->pipe_next;
+            s->pipe_next ^= 1u;
+            Scratch& sc = x ? s->scratch2 : s->scratch;
+            if (s->pipe_used[x]) HIP_TRY(hipStreamWaitEvent(st, s->sel_done[x], 0));
+            s->last_ctl = sc.ctl;
+            HIP_TRY(next_scan_epoch(s, sc, true, st));
+            HIP_TRY(launch_scan_exact(q, a, sc, need, k_eff, s->d_vmax_sq, &n_waves, st));
+            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(hipEventRecord(s->scan_done[x], st));
+            HIP_TRY(hipStreamWaitEvent(s->side, s->scan_done[x], 0));
+            s->one_wg_queries += 1;
+            HIP_TRY(launch_select_final(q, a, sc, false, live, need, k_eff, n_waves, o_rows, o_scores, d_out_n + b,
+                                        o_status, s->side));
+            HIP_TRY(hipEventRecord(s->sel_done[x], s->side));
+            s->pipe_used[x] = true;
+            continue;
+        }
+        s->last_ctl = s->scratch.ctl;
+        HIP_TRY(next_scan_epoch(s, s->scratch, !rescore && !full_select, st));
+        if (rescore) HIP_TRY(launch_scan_stream(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
+        else HIP_TRY(launch_scan_exact(q, a, s->scratch, need, k_eff, s->d_vmax_sq, &n_waves, st));
+        if (e1) HIP_TRY(hipEventRecord(e1, st));
         if (!full_select) {
             s->one_wg_queries += 1;
             HIP_TRY(launch_select_final(q, a, s->scratch, rescore, live, need, k_eff, n_waves, o_rows,
@@ -879,8 +949,18 @@ void trag_store_destroy(trag_store* s) {
     DeviceGuard guard(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipDeviceSynchronize();
+    if (s->side) (void)hipStreamSynchronize(s->side);
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (s->order_ev) (void)hipEventDestroy(s->order_ev);
+    for (int x = 0; x < 2; ++x) {
+        if (s->scan_done[x]) (void)hipEventDestroy(s->scan_done[x]);
+        if (s->sel_done[x]) (void)hipEventDestroy(s->sel_done[x]);
+    }
+    void* set2[] = {s->zero_block2, s->scratch2.cand, s->scratch2.ckeys, s->scratch2.keys, s->scratch2.tmax,
+                    s->scratch2.wmax, s->scratch2.wbest};
+    for (void* p : set2)
+        if (p) (void)hipFree(p);
+    if (s->side) (void)hipStreamDestroy(s->side);
     void* ptrs[] = {s->d_rows, s->d_dead, s->d_vmax_sq, s->d_norm2, s->d_mirror,
                     s->batch.qpad, s->batch.ctls, s->batch.keys, s->batch.tmax, s->batch.cand,
                     s->bf16.qb, s->bf16.thr, s->bf16.ctls, s->bf16.tmax, s->bf16.cand, s->bf16.ckeys, s->bf16.rowc,
@@ -1061,7 +1141,33 @@ trag_status trag_store_search_device(trag_store* s, const float* d_queries, uint
     if (ts != TRAG_OK) return ts;
     const uint32_t mode = choose_mode(s, n_queries, k);
     return enqueue_search(s, d_queries, n_queries, k, mode, d_out_rows, d_out_scores, d_out_n,
-                          d_status, st);
+                          d_status, st, true);
+}
+
+trag_status trag_store_set_pipelined(trag_store* s, int enabled) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    if (enabled && !s->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        for (int x = 0; x < 2; ++x) {
+            HIP_TRY(hipEventCreateWithFlags(&s->scan_done[x], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s->sel_done[x], hipEventDisableTiming));
+        }
+    }
+    if (!enabled && s->side && (s->pipe_used[0] || s->pipe_used[1])) {
+        HIP_TRY(hipStreamSynchronize(s->side));   // (what was enqueued finishes; later calls run on one stream)
+        s->pipe_used[0] = s->pipe_used[1] = false;
+    }
+    s->pipelined = enabled != 0;
+    return TRAG_OK;
+}
+
+trag_status trag_store_fence(trag_store* s, void* hip_stream) {
+    if (!s) return fail(TRAG_INVALID_ARG, "null store");
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    return drain_pipeline(s, (hipStream_t)hip_stream);
 }
 
 trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_t n_queries,

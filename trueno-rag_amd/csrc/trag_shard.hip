@@ -175,6 +175,7 @@ struct trag_shard_group {
     hipStream_t side = nullptr;     // exchange stream (overlap mode) and the host entry's stream
     ExchangeSlot slot[2];
     uint32_t next = 0;
+    trag_store* piped = nullptr;    // the local store this group has switched to pipelined mode (overlap)
     uint32_t* h_pack = nullptr;     // pinned: records of the host entry, then its merged results
     size_t h_words = 0;
     std::mutex mu;
@@ -289,6 +290,12 @@ trag_status trag_shard_search_device(trag_shard_group* g, trag_store* local, uin
     g->next ^= 1u;
     // the exchange that used this slot two calls ago may still be reading it on the side stream
     if (sl.used) SH_TRY(hipStreamWaitEvent(st, sl.done, 0));
+    // overlap mode: the select of a single-query step leaves the stream the scans run on as well
+    if (g->cfg.overlap && g->piped != local) {
+        trag_status tp = trag_store_set_pipelined(local, 1);
+        if (tp != TRAG_OK) return tp;
+        g->piped = local;
+    }
     // A rank whose local search cannot be enqueued still takes part in the collective -- its peers have
     // entered it or are about to, and an all-gather one rank never joins hangs them all: it sends
     // records that hold no row and carry status 3, so every rank sees the query as unfinished, and
@@ -301,6 +308,9 @@ trag_status trag_shard_search_device(trag_shard_group* g, trag_store* local, uin
         SH_TRY(hipEventRecord(sl.searched, st));
         SH_TRY(hipStreamWaitEvent(g->side, sl.searched, 0));
         xs = g->side;
+        // (a pipelined store has this call's select on its own side stream, not on st)
+        trag_status tf = trag_store_fence(local, xs);
+        if (tf != TRAG_OK) return tf;
     }
     const size_t words = (size_t)n_queries * rec_words(k);
     if (local_ts == TRAG_OK)

@@ -230,6 +230,14 @@ class VectorStore:
             C.c_void_p(d_scores_ptr), C.c_void_p(d_n_ptr), C.c_void_p(d_status_ptr) if d_status_ptr else None,
             C.c_void_p(stream) if stream else None), self._config.dimension, self._config.dimension)
 
+    def set_pipelined(self, enabled: bool) -> None:
+        """Single-query device-entry searches overlap their select with the next query's scan; outputs
+        are valid on a stream after fence(stream)."""
+        _abi.check(_abi.lib().trag_store_set_pipelined(self._h, 1 if enabled else 0))
+
+    def fence(self, stream: int = 0) -> None:
+        _abi.check(_abi.lib().trag_store_fence(self._h, C.c_void_p(stream) if stream else None))
+
     def search_device_noalloc(self, d_queries_ptr: int, n_queries: int, k: int, d_rows_ptr: int,
                               d_scores_ptr: int, d_n_ptr: int, d_status_ptr: int = 0, stream: int = 0) -> None:
         """search_device for callers that cannot allocate: exact single-query scans whose scratch is

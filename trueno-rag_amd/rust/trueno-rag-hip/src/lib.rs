@@ -23,6 +23,8 @@ extern "C" {
     fn trag_store_insert(s: *mut TragStore, rows: *const f32, n: u64, dim: u32, first: *mut u32) -> i32;
     fn trag_store_overwrite(s: *mut TragStore, row: u32, v: *const f32, dim: u32) -> i32;
     fn trag_store_remove(s: *mut TragStore, row: u32) -> i32;
+    fn trag_store_set_pipelined(s: *mut TragStore, enabled: i32) -> i32;
+    fn trag_store_fence(s: *mut TragStore, hip_stream: *mut c_void) -> i32;
     fn trag_store_len(s: *const TragStore) -> u64;
     fn trag_store_rows(s: *const TragStore) -> u64;
     fn trag_store_set_bf16_mirror(s: *mut TragStore, enabled: i32) -> i32;
