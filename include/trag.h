@@ -21,9 +21,14 @@
  *    thread is available from trag_last_error().
  *  - Thread contract mirrors &self / &mut self: searches on one handle may be
  *    issued concurrently; insert/overwrite/remove/reserve need exclusive access.
- *    A handle owns ONE search scratch, so its searches run one after the other:
- *    the host-pointer entries hold an internal lock until their results are
- *    back; the `_device` entries hold it while they enqueue, and a call that
+ *    A handle's primary search scratch holds one search at a time: the
+ *    host-pointer entries hold an internal lock until their results are back --
+ *    but a host-pointer search of ONE query that finds the lock taken runs
+ *    beside its holder in one of three spare contexts (own stream, scratch and
+ *    staging; the plain route only: exact-order scan, nothing pending), so four
+ *    threads on one handle overlap on the GPU (10 000 x 384: 3.2 x the queries
+ *    per second of one thread); the `_device` entries hold the lock while they
+ *    enqueue, and a call that
  *    arrives on another stream than the handle's previous call (a caller's
  *    stream, then the handle's own, or two caller streams) first makes the new
  *    stream wait for the work the previous call enqueued. A stream passed to a

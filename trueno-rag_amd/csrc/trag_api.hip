@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -123,6 +124,25 @@ struct trag_store {
     // Pipelined single-query searches (trag_store_set_pipelined): two scratch sets alternate, the scan
     // of a query runs on the caller's stream and its one-workgroup select on `side`, beside the next
     // query's scan; sel_done[x] marks the end of the last select that used set x.
+    // Host-entry searches from several threads: a thread that finds the handle busy takes one of a few
+    // spare search contexts (own stream, scratch set and staging) instead of waiting -- search(&self)
+    // is concurrent in the reference (src/index.rs:386). Created on first use.
+    struct SearchCtx {
+        Scratch sc{};
+        void* zero_block = nullptr;
+        uint64_t keys_cap = 0;
+        hipStream_t stream = nullptr;
+        float* d_q = nullptr;
+        float* h_q = nullptr;         // pinned
+        uint32_t* d_out = nullptr;    // rows [k] | scores [k] | count | status
+        uint32_t* h_out = nullptr;    // pinned
+        uint64_t out_words = 0;
+        bool busy = false;
+    };
+    static constexpr int POOL = 3;
+    SearchCtx pool[POOL];
+    std::mutex pool_mu;
+    bool pool_closed = false;      // a call that changes the store is running: no search beside it
     bool pipelined = false;
     Scratch scratch2{};
     void* zero_block2 = nullptr;
@@ -142,6 +162,32 @@ struct trag_store {
 };
 
 namespace {
+
+// Held (with s->mu) by every call that changes the store or frees what searches read: no spare
+// context is handed out while it lives, and it waits for the ones in use. Searches beside a change
+// are the caller's error (&mut self in the reference), but they stay safe, as they were when one
+// lock serialised everything.
+struct PoolGate {
+    trag_store* s;
+    bool reopen;
+    explicit PoolGate(trag_store* st, bool reopen_ = true) : s(st), reopen(reopen_) {
+        for (;;) {
+            {
+                std::lock_guard<std::mutex> lk(s->pool_mu);
+                s->pool_closed = true;
+                bool busy = false;
+                for (auto& c : s->pool) busy = busy || c.busy;
+                if (!busy) return;
+            }
+            std::this_thread::yield();
+        }
+    }
+    ~PoolGate() {
+        if (!reopen) return;
+        std::lock_guard<std::mutex> lk(s->pool_mu);
+        s->pool_closed = false;
+    }
+};
 
 trag_status grow_rows(trag_store* s, uint64_t want_rows) {
     if (want_rows <= s->cap_rows) return TRAG_OK;
@@ -214,17 +260,20 @@ trag_status grow_rows(trag_store* s, uint64_t want_rows) {
 
 // One search scratch set (the handle has one; a pipelined handle two). A set that must grow is only
 // replaced once nothing can still be using it: the caller has drained the pipeline.
-trag_status ensure_scratch_set(trag_store* s, Scratch& sc, void*& zero_block, uint64_t& keys_cap) {
+trag_status ensure_scratch_set(trag_store* s, Scratch& sc, void*& zero_block, uint64_t& keys_cap,
+                               hipStream_t init_stream, bool shared_state = true) {
     if (!sc.cand) HIP_TRY(hipMalloc(&sc.cand, CAND_CAP * sizeof(uint32_t)));
     if (!sc.ckeys) HIP_TRY(hipMalloc(&sc.ckeys, CAND_CAP * sizeof(uint32_t)));
-    if (!s->h_events) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_events), 64, hipHostMallocMapped));
-        *s->h_events = 0u;
-    }
-    if (!sc.events) {
-        void* dp = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&dp, s->h_events, 0));
-        sc.events = static_cast<uint32_t*>(dp);
+    if (shared_state) {   // (a spare context of a concurrent search touches nothing the handle's lock guards)
+        if (!s->h_events) {
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_events), 64, hipHostMallocMapped));
+            *s->h_events = 0u;
+        }
+        if (!sc.events) {
+            void* dp = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&dp, s->h_events, 0));
+            sc.events = static_cast<uint32_t*>(dp);
+        }
     }
     if (keys_cap < s->cap_rows || !zero_block) {
         void* old[] = {sc.keys, sc.tmax, zero_block};
@@ -234,22 +283,23 @@ trag_status ensure_scratch_set(trag_store* s, Scratch& sc, void*& zero_block, ui
         sc.tmax = nullptr;
         zero_block = nullptr;
         keys_cap = 0;
-        s->last_ctl = nullptr;
+        if (shared_state) s->last_ctl = nullptr;
         const size_t ctl_bytes = 256;  // SearchCtl padded
         static_assert(sizeof(SearchCtl) <= 256, "control block grew");
-        s->zero_bytes = ctl_bytes + HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
-        HIP_TRY(hipMalloc(&zero_block, s->zero_bytes));
+        const size_t zero_bytes = ctl_bytes + HIST_LEVELS * HIST_BINS * sizeof(uint32_t);
+        if (shared_state) s->zero_bytes = zero_bytes;
+        HIP_TRY(hipMalloc(&zero_block, zero_bytes));
         // stream-ordered clear, finished before any stream can use the block (a plain
         // hipMemset on the null stream is not ordered against non-blocking streams)
-        HIP_TRY(hipMemsetAsync(zero_block, 0, s->zero_bytes, s->stream));
-        HIP_TRY(hipStreamSynchronize(s->stream));
+        HIP_TRY(hipMemsetAsync(zero_block, 0, zero_bytes, init_stream));
+        HIP_TRY(hipStreamSynchronize(init_stream));
         sc.ctl = reinterpret_cast<SearchCtl*>(zero_block);
         sc.hist = reinterpret_cast<uint32_t*>(static_cast<char*>(zero_block) + ctl_bytes);
         if (!sc.wmax) HIP_TRY(hipMalloc(&sc.wmax, WMAX_CAP * sizeof(uint32_t)));
         if (!sc.wbest) {
             HIP_TRY(hipMalloc(&sc.wbest, SPARSE_WAVES * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(sc.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), s->stream));
-            HIP_TRY(hipStreamSynchronize(s->stream));
+            HIP_TRY(hipMemsetAsync(sc.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), init_stream));
+            HIP_TRY(hipStreamSynchronize(init_stream));
         }
         HIP_TRY(hipMalloc(&sc.keys, (size_t)s->cap_rows * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&sc.tmax, ((size_t)s->cap_rows / 64 + 1) * sizeof(uint32_t)));
@@ -271,8 +321,8 @@ trag_status ensure_scratch(trag_store* s) {
         HIP_TRY(hipStreamSynchronize(s->side));
         s->pipe_used[0] = s->pipe_used[1] = false;
     }
-    trag_status ts = ensure_scratch_set(s, s->scratch, s->zero_block, s->keys_cap);
-    if (ts == TRAG_OK && s->pipelined) ts = ensure_scratch_set(s, s->scratch2, s->zero_block2, s->keys_cap2);
+    trag_status ts = ensure_scratch_set(s, s->scratch, s->zero_block, s->keys_cap, s->stream);
+    if (ts == TRAG_OK && s->pipelined) ts = ensure_scratch_set(s, s->scratch2, s->zero_block2, s->keys_cap2, s->stream);
     return ts;
 }
 
@@ -946,6 +996,7 @@ trag_status trag_store_create(const trag_config* cfg, trag_store** out) {
 
 void trag_store_destroy(trag_store* s) {
     if (!s) return;
+    PoolGate gate(s, false);
     DeviceGuard guard(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     (void)hipDeviceSynchronize();
@@ -955,6 +1006,15 @@ void trag_store_destroy(trag_store* s) {
     for (int x = 0; x < 2; ++x) {
         if (s->scan_done[x]) (void)hipEventDestroy(s->scan_done[x]);
         if (s->sel_done[x]) (void)hipEventDestroy(s->sel_done[x]);
+    }
+    for (auto& c : s->pool) {
+        if (c.stream) (void)hipStreamSynchronize(c.stream);
+        void* cp[] = {c.zero_block, c.sc.cand, c.sc.ckeys, c.sc.keys, c.sc.tmax, c.sc.wmax, c.sc.wbest, c.d_q, c.d_out};
+        for (void* p : cp)
+            if (p) (void)hipFree(p);
+        if (c.h_q) (void)hipHostFree(c.h_q);
+        if (c.h_out) (void)hipHostFree(c.h_out);
+        if (c.stream) (void)hipStreamDestroy(c.stream);
     }
     void* set2[] = {s->zero_block2, s->scratch2.cand, s->scratch2.ckeys, s->scratch2.keys, s->scratch2.tmax,
                     s->scratch2.wmax, s->scratch2.wbest};
@@ -989,6 +1049,7 @@ uint64_t trag_store_rows(const trag_store* s) { return s ? s->n_rows : 0; }
 trag_status trag_store_reserve(trag_store* s, uint64_t rows) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
+    PoolGate gate(s);
     DeviceGuard guard(s->device);
     return grow_rows(s, rows);
 }
@@ -1001,6 +1062,7 @@ trag_status trag_store_insert(trag_store* s, const float* rows, uint64_t n, uint
         return fail(TRAG_DIM_MISMATCH, "dimension mismatch: expected " + std::to_string(s->cfg.dim) +
                                            ", got " + std::to_string(dim));
     std::lock_guard<std::mutex> lk(s->mu);
+    PoolGate gate(s);
     DeviceGuard guard(s->device);
     if (out_first_row) *out_first_row = (uint32_t)s->n_rows;
     if (n == 0) return TRAG_OK;
@@ -1047,6 +1109,7 @@ trag_status trag_store_overwrite(trag_store* s, uint32_t row, const float* vec, 
         return fail(TRAG_DIM_MISMATCH, "dimension mismatch: expected " + std::to_string(s->cfg.dim) +
                                            ", got " + std::to_string(dim));
     std::lock_guard<std::mutex> lk(s->mu);
+    PoolGate gate(s);
     if (row >= s->n_rows) return fail(TRAG_INVALID_ARG, "row out of range");
     if ((s->h_dead[row >> 5] >> (row & 31)) & 1u) return fail(TRAG_INVALID_ARG, "row was removed");
     DeviceGuard guard(s->device);
@@ -1061,6 +1124,7 @@ trag_status trag_store_overwrite(trag_store* s, uint32_t row, const float* vec, 
 trag_status trag_store_remove(trag_store* s, uint32_t row) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
+    PoolGate gate(s);
     if (row >= s->n_rows) return fail(TRAG_INVALID_ARG, "row out of range");
     uint32_t& w = s->h_dead[row >> 5];
     if ((w >> (row & 31)) & 1u) return fail(TRAG_INVALID_ARG, "row already removed");
@@ -1083,6 +1147,7 @@ trag_status trag::store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
                                        uint64_t row_step, uint32_t* out_first_row) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
+    PoolGate gate(s);
     DeviceGuard guard(s->device);
     if (out_first_row) *out_first_row = (uint32_t)s->n_rows;
     if (n == 0) return TRAG_OK;
@@ -1102,6 +1167,82 @@ trag_status trag::store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed,
     s->n_live += n;
     return TRAG_OK;
 }
+
+namespace {
+
+// Host-entry search of ONE query by a thread that found the handle busy: runs in a spare context
+// (own stream, scratch set, staging) without the handle's lock, beside whatever the lock's holder has
+// on the GPU. Takes only the plain route -- exact-order scan, one-workgroup select, nothing pending,
+// nothing to learn -- and answers false for everything else (and when no context is free or a query
+// does not finish there): the caller then waits for the lock and takes the usual path. Reads of the
+// store's rows and counts need no lock: insert / overwrite / remove need exclusive access by contract
+// (&mut self in the reference), so no search runs beside them.
+bool search_one_concurrent(trag_store* s, const float* query, uint32_t dim, uint32_t k, uint32_t* out_rows,
+                           float* out_scores, uint32_t* out_n, trag_status* result) {
+    const uint64_t live64 = s->n_live;
+    if (k == 0 || live64 == 0 || s->dirty_from < s->n_rows || s->profiling) return false;
+    const uint32_t live = (uint32_t)live64;
+    const uint32_t k_eff = std::min<uint32_t>(k, live);
+    if (k_eff > CAND_CAP - STREAM_SLACK) return false;
+    if (choose_mode(s, 1, k) != TRAG_SCAN_EXACT || plan_full_select(s)) return false;
+    trag_store::SearchCtx* cx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(s->pool_mu);
+        if (!s->pool_closed)
+            for (auto& c : s->pool)
+                if (!c.busy) { c.busy = true; cx = &c; break; }
+    }
+    if (!cx) return false;
+    auto release = [&]() { std::lock_guard<std::mutex> lk(s->pool_mu); cx->busy = false; };
+    DeviceGuard guard(s->device);
+    auto run = [&]() -> trag_status {
+        if (!cx->stream) HIP_TRY(hipStreamCreateWithFlags(&cx->stream, hipStreamNonBlocking));
+        trag_status ts = ensure_scratch_set(s, cx->sc, cx->zero_block, cx->keys_cap, cx->stream, false);
+        if (ts != TRAG_OK) return ts;
+        if (!cx->d_q) {
+            HIP_TRY(hipMalloc(&cx->d_q, (size_t)dim * sizeof(float)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&cx->h_q), (size_t)dim * sizeof(float), hipHostMallocDefault));
+        }
+        const uint64_t words = 2ull * k_eff + 2;
+        if (words > cx->out_words) {
+            if (cx->d_out) (void)hipFree(cx->d_out);
+            if (cx->h_out) (void)hipHostFree(cx->h_out);
+            cx->d_out = cx->h_out = nullptr;
+            cx->out_words = 0;
+            const uint64_t cap = std::max<uint64_t>(words, 256);
+            HIP_TRY(hipMalloc(&cx->d_out, cap * sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&cx->h_out), cap * sizeof(uint32_t), hipHostMallocDefault));
+            cx->out_words = cap;
+        }
+        std::memcpy(cx->h_q, query, (size_t)dim * sizeof(float));
+        HIP_TRY(hipMemcpyAsync(cx->d_q, cx->h_q, (size_t)dim * sizeof(float), hipMemcpyHostToDevice, cx->stream));
+        ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+        cx->sc.epoch = 0;   // every key stored: no tag to manage beside the handle's own scans
+        uint32_t n_waves = 0;
+        uint32_t* d_rows = cx->d_out;
+        float* d_scores = reinterpret_cast<float*>(cx->d_out + k_eff);
+        uint32_t* d_n = cx->d_out + 2 * (size_t)k_eff;
+        HIP_TRY(launch_scan_exact(cx->d_q, a, cx->sc, k_eff, k_eff, s->d_vmax_sq, &n_waves, cx->stream));
+        HIP_TRY(launch_select_final(cx->d_q, a, cx->sc, false, live, k_eff, k_eff, n_waves, d_rows, d_scores, d_n,
+                                    d_n + 1, cx->stream));
+        HIP_TRY(hipMemcpyAsync(cx->h_out, cx->d_out, words * sizeof(uint32_t), hipMemcpyDeviceToHost, cx->stream));
+        HIP_TRY(hipStreamSynchronize(cx->stream));
+        return TRAG_OK;
+    };
+    const trag_status ts = run();
+    if (ts != TRAG_OK) { release(); *result = ts; return true; }
+    const uint32_t* h = cx->h_out;
+    const uint32_t n = h[2 * (size_t)k_eff], status = h[2 * (size_t)k_eff + 1];
+    if (status != ST_OK) { release(); return false; }   // (crowded bin: the locked path repeats it and learns)
+    std::memcpy(out_rows, h, (size_t)n * sizeof(uint32_t));
+    std::memcpy(out_scores, h + k_eff, (size_t)n * sizeof(float));
+    *out_n = n;
+    release();
+    *result = TRAG_OK;
+    return true;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1180,7 +1321,12 @@ trag_status trag_store_search_batch(trag_store* s, const float* queries, uint32_
     if (n_queries == 0) return TRAG_OK;
     if (!queries || !out_n || (k && (!out_rows || !out_scores)))
         return fail(TRAG_INVALID_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(s->mu);
+    std::unique_lock<std::mutex> lk(s->mu, std::try_to_lock);
+    if (!lk.owns_lock()) {   // another thread is searching: one query may run beside it (see above)
+        trag_status tc = TRAG_OK;
+        if (n_queries == 1 && search_one_concurrent(s, queries, dim, k, out_rows, out_scores, out_n, &tc)) return tc;
+        lk.lock();
+    }
     if (k == 0 || s->n_live == 0) {
         for (uint32_t b = 0; b < n_queries; ++b) out_n[b] = 0;
         return TRAG_OK;
@@ -1329,6 +1475,7 @@ trag_status trag_store_set_scan_mode(trag_store* s, uint32_t scan_mode) {
 trag_status trag_store_set_bf16_mirror(trag_store* s, int enabled) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
+    PoolGate gate(s);
     DeviceGuard guard(s->device);
     if (!enabled) {
         if (s->d_mirror) {
