@@ -12,8 +12,9 @@ OUT=$ROOT/trueno-rag_amd/lib_var/$N
 mkdir -p $OUT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-result -I$ROOT/include -I$ROOT/trueno-rag_amd/csrc"
 cd $ROOT/trueno-rag_amd/csrc
-for F in $FILES; do /opt/rocm/bin/hipcc $FLAGS "$@" -c $F -o $OUT/${F%.hip}.o & done
+for F in $FILES; do rm -f $OUT/${F%.hip}.o; /opt/rocm/bin/hipcc $FLAGS "$@" -c $F -o $OUT/${F%.hip}.o & done
 wait
+for F in $FILES; do [ -f $OUT/${F%.hip}.o ] || { echo "compile of $F failed: no variant built"; rm -f $OUT/libtrag.so; exit 1; }; done
 L=$ROOT/trueno-rag_amd/lib
 OBJS=""
 for O in trag_api trag_kernels trag_stream trag_batch trag_bf16 trag_qstat trag_mirror trag_bm25 trag_shard trag_fuse_device trag_fuse trag_embed trag_error; do
