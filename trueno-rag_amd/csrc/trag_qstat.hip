@@ -50,6 +50,13 @@
 #ifndef QS_FLUSH_MIN
 #define QS_FLUSH_MIN 48
 #endif
+// Staging loads by inline assembly (scalar base + 32-bit lane offset, waited for by count) instead of
+// compiler-emitted loads with 64-bit vector address arithmetic per piece: 1.25 M x 384 x 1000 queries,
+// sample + full pass 1.150 -> 1.124 ms from the f32 rows, 0.950 -> 0.941 ms from the mirror (same device,
+// same run). -DQS_ASM_LOADS=0 for the compiler's loads.
+#ifndef QS_ASM_LOADS
+#define QS_ASM_LOADS 1
+#endif
 
 namespace trag {
 
@@ -281,14 +288,40 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     const uint32_t voff = (uint32_t)tid * 16u;
     const uint32_t rc_off = (uint32_t)(tid & 31) * 8u;
     auto issue_piece = [&](int k, int i, uint32_t row0) __attribute__((always_inline)) {
+#ifdef QS_EXP_NOGLOAD
+        return;   // (ablation: LDS is written from registers that are never refreshed)
+#endif
         const char* base = src + (size_t)row0 * ROW_BYTES + (size_t)(i * NT) * 16u;   // (uniform)
+#if QS_ASM_LOADS && defined(__HIP_DEVICE_COMPILE__)
+        // scalar base + 32-bit lane offset: no 64-bit vector address arithmetic per piece. Not known to the
+        // compiler as loads: write_piece waits for them by count.
+        if (NTL) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(pre[k][i]) : "v"(voff), "s"(base) : "memory");
+        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pre[k][i]) : "v"(voff), "s"(base) : "memory");
+        if (i == 0) {
+            const char* rb = reinterpret_cast<const char*>(rowc_g) + (size_t)row0 * 8u;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(pre_rc[k]) : "v"(rc_off), "s"(rb) : "memory");
+        }
+#else
         const u32x4* p = reinterpret_cast<const u32x4*>(base + voff);
         pre[k][i] = NTL ? __builtin_nontemporal_load(p) : *p;
         if (i == 0)
             pre_rc[k] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(rowc_g) + (size_t)row0 * 8u + rc_off);
+#endif
     };
     // (scale, shift): see row_scale_shift (trag_device.h)
     auto write_piece = [&](int k, int i, int sl, uint32_t) __attribute__((always_inline)) {
+#ifdef QS_EXP_NOLDSWRITE
+        // (ablation: the loads are issued and waited for, nothing is written to LDS)
+        asm volatile("" ::"v"(pre[k][i]));
+        if (i == 0) asm volatile("" ::"v"(pre_rc[k].x), "v"(pre_rc[k].y));
+        return;
+#endif
+#if QS_ASM_LOADS && defined(__HIP_DEVICE_COMPILE__)
+        // a piece was loaded DP steps ago; since then the wave has issued DP (NL + 1) - 1 younger loads
+        // (pieces and the rows' constants, in that order behind piece 0), and loads return in order
+        if (i == 0) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(pre[k][i]), "+v"(pre_rc[k]) : "n"(DP * (NL + 1) - 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pre[k][i]) : "n"(DP * (NL + 1) - 1) : "memory");
+#endif
         if (MIR) {
             *reinterpret_cast<u32x4*>(&img[sl][loff[i]]) = pre[k][i];
         } else {
@@ -491,6 +524,7 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         const uint32_t row0 = unit[0] * rows_per_unit + 32u * (uint32_t)sub;
 #pragma unroll
         for (int i = 0; i < NL; ++i) issue_piece(0, i, row0);
+        drain_vmem();
 #pragma unroll
         for (int i = 0; i < NL; ++i) write_piece(0, i, sub, row0);
     }
