@@ -155,11 +155,18 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     const uint32_t n_units = (n_tiles + tile_step - 1) / tile_step;
     if (strm >= n_units) return;
     const uint32_t n_mine = (n_units - strm + n_streams - 1) / n_streams;
-    // The G workgroups of a stream walk its units in rotated order inside groups of G (group c:
-    // c G + (j + g) % G for j = 0 .. G - 1), so that at any time they ask memory for G different
-    // tiles -- G times the bytes in flight -- and each tile comes from HBM once and from L2 / the
-    // Infinity Cache for the other G - 1. A last, partial group is walked in plain order.
+    // The G workgroups of a stream walk its units in the same order. (With QS_ROTATE: in rotated order
+    // inside groups of G -- group c: c G + (j + g) % G for j = 0 .. G - 1 -- so that at any time they ask
+    // memory for G different tiles; a last, partial group is walked in plain order.)
+    // (Measured, 1.25 M x 384 x 1000 queries, G = 4: walked in rotated order the f32 rows cost 3.61 GB of
+    // FETCH_SIZE for 1.92 GB of corpus and the mirror 1.115 GB for 0.96; in plain order -- the G workgroups
+    // ask for the same tile at about the same time, one miss and G - 1 hits -- 2.63 GB and 1.014 GB, and the
+    // step is 2 % / 1 % shorter. -DQS_ROTATE brings the rotation back.)
+#ifdef QS_ROTATE
     const uint32_t n_rot = (n_mine / G) * G;
+#else
+    const uint32_t n_rot = 0u;
+#endif
     // the units in this workgroup's order, one after the other (no division in the loop); past the
     // last one: NO_UNIT
     constexpr uint32_t NO_UNIT = 0xFFFFFFFFu;
