@@ -314,6 +314,10 @@ def main():
             mine_info = dict(group.info(), rank=rank, local_device=local)
         except Exception as e:  # noqa: BLE001 -- an RCCL without the query calls: say so in the record
             mine_info = {"rank": rank, "local_device": local, "error": str(e)}
+        props = torch.cuda.get_device_properties(local)
+        mine_info.update({"host": os.uname().nodename, "pid": os.getpid(), "gpu": props.name,
+                          "pci_bus_id": getattr(props, "pci_bus_id", None),
+                          "gpu_uuid": str(getattr(props, "uuid", "")) or None})
         ranks_info = [mine_info]
         if world > 1:
             ranks_info = [None] * world
