@@ -60,7 +60,10 @@ def test_one_rank_step_is_one_c_call_over_rccl():
     assert "RCCL all-gather" in r["config"]["exchange"]
     # what RCCL itself reports: the communicator spans as many ranks as the run has, on this rank's device
     assert r["config"]["rccl_version"] >= 20000 and r["config"]["rccl_comm_world"] == r["n_gpus"] == 1
-    assert r["config"]["ranks"] == [{"comm_world": 1, "comm_rank": 0, "comm_device": 0, "rank": 0, "local_device": 0}]
+    (mine,) = r["config"]["ranks"]
+    assert {k: mine[k] for k in ("comm_world", "comm_rank", "comm_device", "rank", "local_device")} == \
+        {"comm_world": 1, "comm_rank": 0, "comm_device": 0, "rank": 0, "local_device": 0}
+    assert mine["pid"] > 0 and mine["host"] and mine["gpu"]        # which process on which GPU ran the rank
     assert r["parity"]["uncertified_queries"] == 0 and r["parity"]["device_merge_equals_host_merge"] is True
     assert r["parity"]["sharded_equals_single_store"] is True
     assert r["parity"]["single_store_check"]["batch_1000_identical"] is True
