@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--host", action="store_true",
                     help="time the host-pointer entry (trag_store_search: query from host memory, results to host "
                          "memory, synchronous) instead of the device-resident one; the shape of the smallest benchmark configuration (10 000 x 384)")
+    ap.add_argument("--pipeline", type=int, choices=(1, 2), default=None,
+                    help="pipelined mode of single-query steps: 2 (default) deferred selects, 1 side stream")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="single-query steps: keep the select on the stream of the scans (by default the handle is in "
                          "pipelined mode: the select of query i runs beside the scan of query i+1, results fenced)")
@@ -144,8 +146,13 @@ def main():
     if args.mirror:
         store.set_bf16_mirror(True)
     pipelined = not args.no_pipeline and args.batch == 1 and not args.host and not args.hybrid
-    if pipelined:   # (a sharded run's exchange group switches it on itself: overlap mode)
-        store.set_pipelined(True)
+    # 2: the select of query i rides in the launch of query i + 1's scan (one launch a query); 1: it runs
+    # on the handle's side stream beside that scan -- what a sharded run's exchange group switches on
+    # itself (overlap mode: the exchange needs each query's results while the next scan runs)
+    exchanging = world > 1 or bool(os.environ.get("TRAG_BENCH_FORCE_EXCHANGE"))
+    pipe_mode = (args.pipeline if args.pipeline is not None else (1 if exchanging else 2)) if pipelined else 0
+    if pipelined:
+        store.set_pipelined(pipe_mode)
 
     B = args.batch
     n_q = (args.steps + args.warmup) * B
@@ -243,6 +250,7 @@ def main():
             done = torch.cuda.Event()
             done.record(stream)
             side.wait_event(done)
+            store.fence(side.cuda_stream)   # (a pipelined handle's select is not on `stream`)
             with torch.cuda.stream(side):
                 ex.exchange(out_rows[i:i + B], out_scores[i:i + B], out_n[i:i + B], row0,
                             m_rows[i:i + B], m_scores[i:i + B], m_n[i:i + B], side.cuda_stream)
@@ -446,8 +454,10 @@ def main():
                        "bf16_mirror": bool(args.mirror),
                        "entry": "host pointers (PCIe + synchronisation inside every step)" if args.host
                                 else "device-resident queries and results",
-                       "pipelined": ("select of query i on the handle's side stream beside the scan of query i+1; "
-                                     "all results fenced inside the timed region") if pipelined else None,
+                       "pipelined": (("select of query i as one more workgroup of the launch of query i+1's scan; "
+                                      if pipe_mode == 2 else
+                                      "select of query i on the handle's side stream beside the scan of query i+1; ")
+                                     + "all results fenced inside the timed region") if pipelined else None,
                        "latency_us_per_call": 1e3 * ms_per_step if args.host else None,
                        "path_used": {1: "exact scan (f32, reference order)", 2: "streaming scan + exact re-score",
                                      3: "f32 matrix cores + exact re-score",

@@ -161,18 +161,27 @@ trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint
 
 /* Pipelined single-query searches on the device entry. VectorStore::search (src/index.rs:386-412) is
  * "score every row, then order": on the GPU a scan of the corpus and a one-workgroup select behind
- * it, which runs alone on the device (17 us behind a 235 us scan of 1 M x 384). With pipelining
- * enabled a handle keeps two search scratch sets and its own side stream: the scan of a query runs
- * on the caller's stream, its select on the side stream beside the NEXT query's scan. Only
- * trag_store_search_device calls with one query that take the exact-order scan and the
- * one-workgroup select are pipelined; every other route first waits for the pipeline and then runs
- * on the caller's stream as before. The outputs of a pipelined call (rows, scores, count, status) are
- * written on the side stream: a stream may read them only after trag_store_fence on it. Host-pointer
- * entries are unaffected (they wait for their own results). Costs a second scratch set (8 bytes per
- * row instead of 4). No counterpart in the reference. */
+ * it, which runs alone on the device (17 us behind a 235 us scan of 1 M x 384). A pipelined handle
+ * keeps two search scratch sets and runs the select of a query beside the NEXT query's scan:
+ *   enabled = 1  on the handle's own side stream (events order scan -> select -> the set's next use);
+ *                a query's results exist soon after its own scan -- what an exchange that runs beside
+ *                the next scan needs (trag_shard_config.overlap switches this on);
+ *   enabled = 2  as one more workgroup of the next scan's launch: one launch per query, no event, no
+ *                second stream (1 M x 384: 0.239 ms a query against 0.253 unpipelined and 0.248 with
+ *                mode 1). The select of the LAST query enqueued stays pending inside the handle until
+ *                the next query's launch carries it or trag_store_fence (or any call that takes
+ *                another route, changes the stream or replaces the scratch) launches it on its own.
+ *   enabled = 0  off (what is pending is launched, what runs on the side stream is waited for).
+ * Only trag_store_search_device calls with one query that take the exact-order scan and the
+ * one-workgroup select are pipelined; every other route first settles the pipeline and then runs
+ * on the caller's stream as before. The outputs of a pipelined call (rows, scores, count, status) may
+ * be read on a stream only after trag_store_fence on it, and the output buffers must stay valid until
+ * then. Host-pointer entries are unaffected (they wait for their own results). Costs a second scratch
+ * set (8 bytes per row instead of 4). No counterpart in the reference. */
 trag_status trag_store_set_pipelined(trag_store *s, int enabled);
-/* Makes hip_stream wait for every select the handle has enqueued on its side stream so far (a no-op
- * on a handle that is not pipelined). Enqueues a wait, does not block the host. */
+/* Makes hip_stream wait for every select the handle still owes: a pending one (mode 2) is launched
+ * on the stream of its scan, those on the side stream (mode 1) are waited for. A no-op on a handle
+ * that is not pipelined. Enqueues work and waits, does not block the host. */
 trag_status trag_store_fence(trag_store *s, void *hip_stream);
 
 /* No counterpart in the reference. For callers that cannot allocate device memory -- code

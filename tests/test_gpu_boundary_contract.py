@@ -183,12 +183,14 @@ def test_clone_is_an_independent_copy(trag, oracle):
     assert np.array_equal(rows, er) and store.len() == n - 3 and twin.len() == n - 3
 
 
+@pytest.mark.parametrize("pipe_mode", [1, 2])
 @pytest.mark.parametrize("metric", [0, 1])
-def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metric):
-    """Pipelined mode (trag_store_set_pipelined): the select of query i runs on the handle's side stream
-    beside the scan of query i + 1. 40 single-query searches enqueued back to back on a user stream,
-    a host-entry search and a batch in between (other routes: they wait for the pipeline), a second
-    user stream; outputs are read only after trag_store_fence -- all equal the oracle's."""
+def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metric, pipe_mode):
+    """Pipelined modes (trag_store_set_pipelined): the select of query i runs beside the scan of query
+    i + 1 -- on the handle's side stream (1), or as one more workgroup of that scan's launch (2). 40
+    single-query searches enqueued back to back on a user stream, a host-entry search and a batch in
+    between (other routes: they wait for the pipeline), a second user stream; outputs are read only after
+    trag_store_fence -- all equal the oracle's."""
     import torch
     n, d, k, B = 1_500_000, 64, 10, 40
     store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(metric), device=0,
@@ -203,7 +205,7 @@ def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metri
     status = torch.full((B,), 9, dtype=torch.int32, device="cuda")
     user, other = torch.cuda.Stream(), torch.cuda.Stream()
     torch.cuda.synchronize()
-    store.set_pipelined(True)
+    store.set_pipelined(pipe_mode)
     host = {}
     for b in range(B):
         st = other if b in (17, 18) else user          # a change of stream in the middle of the run
@@ -240,11 +242,13 @@ def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metri
     store.close()
 
 
-def test_pipelined_outputs_are_not_ordered_on_the_callers_stream_without_the_fence(trag, oracle):
+@pytest.mark.parametrize("pipe_mode", [1, 2])
+def test_pipelined_outputs_are_not_ordered_on_the_callers_stream_without_the_fence(trag, oracle, pipe_mode):
     """What the fence is for: in pipelined mode the select writes the outputs on the handle's side stream,
     so a copy enqueued on the caller's stream right behind the call -- no fence -- is not ordered behind
     it and can read the outputs before they are written (it runs as soon as the scan has finished, beside
-    the select). The same copy behind trag_store_fence always sees them."""
+    the select). The same copy behind trag_store_fence always sees them. (Mode 2: the select is not even
+    enqueued before the fence or the next query asks for it.)"""
     import torch
     n, d, k = 3_000_000, 64, 10
     store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0, reserve_rows=n))
@@ -252,7 +256,7 @@ def test_pipelined_outputs_are_not_ordered_on_the_callers_stream_without_the_fen
     q = oracle.synth_rows(174, 0, 1, d)
     dq = torch.from_numpy(q).cuda()
     want_rows, _ = store.search_rows(q[0], k)
-    store.set_pipelined(True)
+    store.set_pipelined(pipe_mode)
     user = torch.cuda.Stream()
     stale_seen, fenced_ok = 0, 0
     for rep in range(8):
@@ -272,4 +276,93 @@ def test_pipelined_outputs_are_not_ordered_on_the_callers_stream_without_the_fen
         fenced_ok += int(late.cpu().tolist() == want_rows.astype(np.int32).tolist())
     assert fenced_ok == 8
     assert stale_seen >= 1, "the unfenced copy was never early: is the select still on the caller's stream?"
+    if pipe_mode == 2:
+        assert stale_seen == 8
     store.close()
+
+
+def _device_query(store, dq, b, d, k, out, stream):
+    rows, scores, cnt, status = out
+    kk = rows.shape[1]
+    store.search_device(dq.data_ptr() + b * d * 4, 1, k, rows.data_ptr() + b * kk * 4, scores.data_ptr() + b * kk * 4,
+                        cnt.data_ptr() + b * 4, status.data_ptr() + b * 4, stream)
+
+
+@pytest.mark.parametrize("d", [64, 10])
+def test_deferred_selects_survive_whatever_comes_between_two_queries(trag, oracle, d):
+    """Mode 2 keeps the select of the last query pending until the next scan's launch carries it. Between
+    two queries: another k, inserts (the pending select belongs to the store as it was), a removal, growth
+    past the reserved capacity (the scratch sets are replaced), a switch of the mode. Every result equals
+    the oracle's on the corpus of its own moment. (d = 10: rows the fused launch does not take -- every
+    select is launched on its own; same results.)"""
+    import torch
+    n, kmax = 40_000, 50
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0, reserve_rows=n + 100))
+    store.fill_synthetic(n, 181)
+    Q = oracle.synth_rows(182, 0, 8, d)
+    dq = torch.from_numpy(Q).cuda()
+    out = (torch.full((8, kmax), -1, dtype=torch.int32, device="cuda"), torch.zeros((8, kmax), device="cuda"),
+           torch.zeros(8, dtype=torch.int32, device="cuda"), torch.full((8,), 9, dtype=torch.int32, device="cuda"))
+    user = torch.cuda.Stream()
+    sp = user.cuda_stream
+    torch.cuda.synchronize()
+    store.set_pipelined(2)
+    corpus = {}
+    ks = [10, 5, 50, 10, 10, 7, 10, 10]
+    corpus[0] = store.read_rows(0, store.rows())
+    _device_query(store, dq, 0, d, ks[0], out, sp)
+    _device_query(store, dq, 1, d, ks[1], out, sp)              # another k, same corpus
+    corpus[1] = corpus[0]
+    extra = oracle.synth_rows(183, 0, 60, d)
+    store.insert_rows(extra[:40])                               # small inserts: deferred themselves
+    corpus[2] = store.read_rows(0, store.rows())
+    _device_query(store, dq, 2, d, ks[2], out, sp)
+    store.remove_row(int(oracle.search(corpus[2], Q[3], 1, 0)[0][0]))   # query 3's best row goes
+    corpus[3] = store.read_rows(0, store.rows())
+    _device_query(store, dq, 3, d, ks[3], out, sp)
+    big = oracle.synth_rows(184, 0, 30_000, d)
+    store.insert_rows(big)                                      # past the reservation: everything is replaced
+    corpus[4] = store.read_rows(0, store.rows())
+    _device_query(store, dq, 4, d, ks[4], out, sp)
+    store.set_pipelined(0)                                      # the pending select is launched by the switch
+    corpus[5] = corpus[4]
+    _device_query(store, dq, 5, d, ks[5], out, sp)
+    store.set_pipelined(2)
+    corpus[6] = corpus[4]
+    _device_query(store, dq, 6, d, ks[6], out, sp)
+    got_host = store.search_rows(Q[7], ks[7])                   # host entry with a select pending
+    store.fence(sp)
+    user.synchronize()
+    torch.cuda.synchronize()
+    rows, scores, cnt, status = (t.cpu().numpy() for t in out)
+    removed = int(oracle.search(corpus[2], Q[3], 1, 0)[0][0])
+
+    def expect(b, c):
+        dead = None
+        if b >= 3:
+            dead = np.zeros(c.shape[0], dtype=np.uint8)
+            dead[removed] = 1
+        return oracle.search(c, Q[b], ks[b], 0, dead)
+
+    for b in range(7):
+        want = expect(b, corpus[b])
+        assert status[b] == 0 and cnt[b] == ks[b], (b, status[b], cnt[b])
+        assert_same_ranking(rows[b, :ks[b]].astype(np.uint32), scores[b, :ks[b]], want[0], want[1], f"query {b}")
+    want = expect(7, corpus[4])
+    assert_same_ranking(got_host[0], got_host[1], want[0], want[1], "host entry")
+    store.close()
+
+
+def test_deferred_select_pending_at_destroy_is_dropped_quietly(trag, oracle):
+    import torch
+    d, k = 64, 10
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0))
+    store.fill_synthetic(20_000, 185)
+    dq = torch.from_numpy(oracle.synth_rows(186, 0, 1, d)).cuda()
+    out = (torch.full((1, k), -1, dtype=torch.int32, device="cuda"), torch.zeros((1, k), device="cuda"),
+           torch.zeros(1, dtype=torch.int32, device="cuda"), torch.full((1,), 9, dtype=torch.int32, device="cuda"))
+    store.set_pipelined(2)
+    _device_query(store, dq, 0, d, k, out, 0)
+    store.close()                                                # no fence: the result is never written
+    torch.cuda.synchronize()
+    assert out[0].cpu().tolist() == [[-1] * k] and out[3].cpu().tolist() == [9]

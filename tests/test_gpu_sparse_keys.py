@@ -106,12 +106,15 @@ def test_sparse_key_stores_change_nothing(trag, oracle, metric):
     assert gathered["0", EXACT] == 0 and gathered["0", MIRROR] == 0, gathered
 
 
-def test_euclidean_long_store_finishes_queries_enqueued_far_ahead(trag, oracle):
+@pytest.mark.parametrize("pipe_mode", [0, 1, 2])
+def test_euclidean_long_store_finishes_queries_enqueued_far_ahead(trag, oracle, pipe_mode):
     """A 2.7 M-row Euclidean store of normalised vectors: nearly every distance shares the coarse score
     bin of the k-th best, which the one-workgroup select used to hand back (status 3) until the handle
     had learned the multi-level plan -- every query enqueued before that came back unfinished. With the
     sparse key stores the scan's own bound cuts the crowd: 200 queries enqueued ahead of the GPU, on a
-    fresh handle, all finish, with the oracle's rows and score bits."""
+    fresh handle, all finish, with the oracle's rows and score bits -- with the select behind its scan
+    (0), on the handle's side stream (1), or riding in the next scan's launch (2: the bound it reads is its
+    own scratch set's, tagged with its own scan's epoch, while the next scan publishes into the other)."""
     import torch
     n, d, k, B = 2_700_000, 64, 10, 200
     st = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(1), device=0, reserve_rows=n))
@@ -123,9 +126,11 @@ def test_euclidean_long_store_finishes_queries_enqueued_far_ahead(trag, oracle):
     cnt = torch.zeros(B, dtype=torch.int32, device="cuda")
     status = torch.full((B,), 9, dtype=torch.int32, device="cuda")
     sp = torch.cuda.current_stream().cuda_stream
+    st.set_pipelined(pipe_mode)
     for b in range(B):      # one query per call, nothing synchronised in between
         st.search_device(dq.data_ptr() + b * d * 4, 1, k, rows.data_ptr() + b * k * 4, scores.data_ptr() + b * k * 4,
                          cnt.data_ptr() + b * 4, status.data_ptr() + b * 4, sp)
+    st.fence(sp)
     torch.cuda.synchronize()
     assert int((status != 0).sum().item()) == 0, status.tolist()
     assert cnt.tolist() == [k] * B

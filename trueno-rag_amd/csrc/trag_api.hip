@@ -151,6 +151,15 @@ struct trag_store {
     hipEvent_t scan_done[2] = {nullptr, nullptr}, sel_done[2] = {nullptr, nullptr};
     bool pipe_used[2] = {false, false};
     uint32_t pipe_next = 0;
+    // Deferred selects (trag_store_set_pipelined(s, 2)): the select of a plain single query is not
+    // launched behind its scan but kept here, and rides as one extra workgroup in the launch of the
+    // NEXT query's scan (other scratch set) -- one launch per query, no event, no second stream. Anything
+    // that needs the results first (trag_store_fence, any other route, a change of stream, a scratch
+    // set about to be replaced) launches it on its own, on the stream its scan ran on.
+    bool deferred = false, has_pend = false;
+    PrevSelect pend{};
+    hipStream_t pend_stream = nullptr;
+    hipEvent_t pend_ev = nullptr;
     std::mutex mu;
     trag_search_stats stats{};
     // optional scan timing
@@ -308,8 +317,39 @@ trag_status ensure_scratch_set(trag_store* s, Scratch& sc, void*& zero_block, ui
     return TRAG_OK;
 }
 
-// Makes `st` wait for the selects a pipelined handle has on its side stream (no-op otherwise).
+// A deferred select that is still pending: launched now, alone, on the stream its scan ran on.
+trag_status flush_pending(trag_store* s) {
+    if (!s->has_pend) return TRAG_OK;
+    const PrevSelect& p = s->pend;
+    s->has_pend = false;
+    Scratch sc{};
+    sc.ctl = p.ctl;
+    sc.hist = p.hist;
+    sc.keys = const_cast<uint32_t*>(p.keys);
+    sc.tmax = const_cast<uint32_t*>(p.tmax);
+    sc.wmax = const_cast<uint32_t*>(p.wmax);
+    sc.events = p.events;
+    sc.wbest = const_cast<unsigned long long*>(p.wbest);
+    sc.epoch = p.epoch;
+    const ScanArgs a{s->d_rows, s->d_dead, p.n_rows, p.d, s->cfg.metric};
+    HIP_TRY(launch_select_final(p.q, a, sc, false, p.live, p.need, p.k, p.n_waves, p.out_rows, p.out_scores, p.out_n,
+                                p.out_status, s->pend_stream));
+    return TRAG_OK;
+}
+
+// Makes `st` wait for the selects a pipelined handle still owes: a deferred one is launched (and `st`
+// ordered behind it when it is another stream than the scan's), those on the side stream are waited for.
+// No-op on a handle that is not pipelined.
 trag_status drain_pipeline(trag_store* s, hipStream_t st) {
+    if (s->has_pend) {
+        const hipStream_t ps = s->pend_stream;
+        trag_status ts = flush_pending(s);
+        if (ts != TRAG_OK) return ts;
+        if (ps != st) {
+            HIP_TRY(hipEventRecord(s->pend_ev, ps));
+            HIP_TRY(hipStreamWaitEvent(st, s->pend_ev, 0));
+        }
+    }
     for (int x = 0; x < 2; ++x)
         if (s->pipe_used[x]) HIP_TRY(hipStreamWaitEvent(st, s->sel_done[x], 0));
     return TRAG_OK;
@@ -317,12 +357,20 @@ trag_status drain_pipeline(trag_store* s, hipStream_t st) {
 
 trag_status ensure_scratch(trag_store* s) {
     // (a set is replaced when the store has grown: nothing of the pipeline may still be reading it)
-    if ((s->keys_cap < s->cap_rows || (s->pipelined && s->keys_cap2 < s->cap_rows)) && (s->pipe_used[0] || s->pipe_used[1])) {
+    const bool two = s->pipelined || s->deferred;
+    const bool replace = s->keys_cap < s->cap_rows || (two && s->keys_cap2 < s->cap_rows);
+    if (replace && (s->pipe_used[0] || s->pipe_used[1])) {
         HIP_TRY(hipStreamSynchronize(s->side));
         s->pipe_used[0] = s->pipe_used[1] = false;
     }
+    if (replace && s->has_pend) {   // (the pending select reads the set that is about to go)
+        const hipStream_t ps = s->pend_stream;
+        trag_status tp = flush_pending(s);
+        if (tp != TRAG_OK) return tp;
+        HIP_TRY(hipStreamSynchronize(ps));
+    }
     trag_status ts = ensure_scratch_set(s, s->scratch, s->zero_block, s->keys_cap, s->stream);
-    if (ts == TRAG_OK && s->pipelined) ts = ensure_scratch_set(s, s->scratch2, s->zero_block2, s->keys_cap2, s->stream);
+    if (ts == TRAG_OK && two) ts = ensure_scratch_set(s, s->scratch2, s->zero_block2, s->keys_cap2, s->stream);
     return ts;
 }
 
@@ -576,6 +624,11 @@ static hipError_t next_scan_epoch(trag_store* s, Scratch& sc, bool allowed, hipS
     if (++s->scan_epoch == 0u) {   // wrapped: forget every old tag (of both scratch sets, nothing in flight)
         s->scan_epoch = 1;
         if (s->side && (s->pipe_used[0] || s->pipe_used[1])) err = hipStreamSynchronize(s->side);
+        if (err == hipSuccess && s->has_pend) {   // (a deferred select still reads its set's tags)
+            const hipStream_t ps = s->pend_stream;
+            if (flush_pending(s) != TRAG_OK) err = hipErrorUnknown;
+            if (err == hipSuccess) err = hipStreamSynchronize(ps);
+        }
         if (err == hipSuccess) err = hipMemsetAsync(s->scratch.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st);
         if (err == hipSuccess && s->scratch2.wbest)
             err = hipMemsetAsync(s->scratch2.wbest, 0, SPARSE_WAVES * sizeof(unsigned long long), st);
@@ -622,9 +675,9 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     // Pipelined form (device entry of a handle that asked for it, one exact-order query, the
     // one-workgroup select): every other route runs on `st` alone, behind whatever the pipeline still
     // has on the side stream.
-    const bool pipe = may_pipeline && s->pipelined && s->side && n_queries == 1 && mode == TRAG_SCAN_EXACT &&
-                      !full_select && !(k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP);
-    if (!pipe && (s->pipe_used[0] || s->pipe_used[1])) {
+    const bool pipe = may_pipeline && ((s->pipelined && s->side) || s->deferred) && n_queries == 1 &&
+                      mode == TRAG_SCAN_EXACT && !full_select && !(k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP);
+    if (!pipe && (s->pipe_used[0] || s->pipe_used[1] || s->has_pend)) {
         ts = drain_pipeline(s, st);
         if (ts != TRAG_OK) return ts;
     }
@@ -760,6 +813,47 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         uint32_t* o_rows = d_out_rows + (size_t)b * k;
         float* o_scores = d_out_scores + (size_t)b * k;
         uint32_t* o_status = d_status ? d_status + b : nullptr;
+        if (pipe && s->deferred) {
+            // this query's scan, with the previous query's select as one more workgroup of the launch;
+            // this query's select is kept for the next launch (or for whoever needs the results first)
+            const uint32_t x = s->pipe_next;
+            s->pipe_next ^= 1u;
+            Scratch& sc = x ? s->scratch2 : s->scratch;
+            if (s->has_pend && (s->pend.ctl == sc.ctl || s->pend_stream != st || !scan_can_fuse(s->cfg.dim))) {
+                // (cannot ride along: same set, another stream -- order_after_last has ordered the streams
+                // by now --, or a scan form without the extra workgroup)
+                ts = drain_pipeline(s, st);
+                if (ts != TRAG_OK) return ts;
+            }
+            s->last_ctl = sc.ctl;
+            HIP_TRY(next_scan_epoch(s, sc, true, st));
+            HIP_TRY(launch_scan_exact(q, a, sc, need, k_eff, s->d_vmax_sq, &n_waves, st, s->has_pend ? &s->pend : nullptr));
+            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            s->one_wg_queries += 1;
+            PrevSelect& p = s->pend;
+            p.q = q;
+            p.n_rows = a.n_rows;
+            p.d = a.dim;
+            p.live = live;
+            p.need = need;
+            p.k = k_eff;
+            p.n_waves = n_waves;
+            p.ctl = sc.ctl;
+            p.hist = sc.hist;
+            p.keys = sc.keys;
+            p.tmax = sc.tmax;
+            p.wmax = sc.wmax;
+            p.out_rows = o_rows;
+            p.out_scores = o_scores;
+            p.out_n = d_out_n + b;
+            p.out_status = o_status;
+            p.events = sc.events;
+            p.wbest = sc.wbest;
+            p.epoch = sc.wbest ? sc.epoch : 0u;
+            s->has_pend = true;
+            s->pend_stream = st;
+            continue;
+        }
         if (pipe) {
             // scan on the caller's stream, select on the side stream beside the NEXT query's scan; the
             // set's previous select (two queries ago) must have finished before this scan writes into it
@@ -1003,6 +1097,7 @@ void trag_store_destroy(trag_store* s) {
     if (s->side) (void)hipStreamSynchronize(s->side);
     for (auto& ev : s->ev_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (s->order_ev) (void)hipEventDestroy(s->order_ev);
+    if (s->pend_ev) (void)hipEventDestroy(s->pend_ev);
     for (int x = 0; x < 2; ++x) {
         if (s->scan_done[x]) (void)hipEventDestroy(s->scan_done[x]);
         if (s->sel_done[x]) (void)hipEventDestroy(s->sel_done[x]);
@@ -1289,18 +1384,25 @@ trag_status trag_store_set_pipelined(trag_store* s, int enabled) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
-    if (enabled && !s->side) {
+    if (enabled != 0 && enabled != 1 && enabled != 2) return fail(TRAG_INVALID_ARG, "pipelining mode must be 0, 1 or 2");
+    if (enabled == 1 && !s->side) {
         HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         for (int x = 0; x < 2; ++x) {
             HIP_TRY(hipEventCreateWithFlags(&s->scan_done[x], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&s->sel_done[x], hipEventDisableTiming));
         }
     }
-    if (!enabled && s->side && (s->pipe_used[0] || s->pipe_used[1])) {
+    if (enabled == 2 && !s->pend_ev) HIP_TRY(hipEventCreateWithFlags(&s->pend_ev, hipEventDisableTiming));
+    if (enabled != 1 && s->side && (s->pipe_used[0] || s->pipe_used[1])) {
         HIP_TRY(hipStreamSynchronize(s->side));   // (what was enqueued finishes; later calls run on one stream)
         s->pipe_used[0] = s->pipe_used[1] = false;
     }
-    s->pipelined = enabled != 0;
+    if (enabled != 2 && s->has_pend) {   // (a select still owed is launched now, behind its scan)
+        trag_status ts = flush_pending(s);
+        if (ts != TRAG_OK) return ts;
+    }
+    s->pipelined = enabled == 1;
+    s->deferred = enabled == 2;
     return TRAG_OK;
 }
 

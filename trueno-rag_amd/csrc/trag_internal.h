@@ -151,10 +151,33 @@ struct ScanArgs {
 trag_status store_fill_synthetic(trag_store* s, uint64_t n, uint64_t seed, uint64_t first_global_row,
                                  uint64_t row_step, uint32_t* out_first_row);
 
+// What the one-workgroup select of a single exact-order query needs: kept by a handle whose selects are
+// deferred (the select of query i runs as one extra workgroup of query i + 1's scan launch, or alone
+// when something needs the results first).
+struct PrevSelect {
+    const float* q = nullptr;
+    uint32_t n_rows = 0, d = 0, live = 0, need = 0, k = 0, n_waves = 0;
+    SearchCtl* ctl = nullptr;
+    uint32_t* hist = nullptr;
+    const uint32_t* keys = nullptr;
+    const uint32_t* tmax = nullptr;
+    const uint32_t* wmax = nullptr;
+    uint32_t* out_rows = nullptr;
+    float* out_scores = nullptr;
+    uint32_t* out_n = nullptr;
+    uint32_t* out_status = nullptr;
+    uint32_t* events = nullptr;
+    const unsigned long long* wbest = nullptr;
+    uint32_t epoch = 0;
+};
+
 // ---- kernel launchers (trag_kernels.hip) ----
 // the scans report the number of waves of their grid (tile t is scanned by wave t % n_waves)
+// prev (scan_can_fuse(dim) only): that select rides in the scan's launch as one more workgroup
+bool scan_can_fuse(uint32_t dim);
 hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                             uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st);
+                             uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st,
+                             const PrevSelect* prev = nullptr);
 hipError_t launch_scan_stream(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
                               uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st);
 // n_queries > 1: one workgroup per query of a multi-query scan (scratch strided by *ms, the

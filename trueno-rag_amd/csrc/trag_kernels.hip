@@ -75,15 +75,30 @@ __device__ __forceinline__ float finish_score(float acc0, float acc1, float na) 
 // 2.270 / 2.264 ms with, 2.297 / 2.272 without), and 64-float chunks do not help long rows
 // either (2M x 4096: 5.054 ms with 32-float chunks, 5.062 with 64; 1M x 1536: 0.926 / 0.935).
 // ---------------------------------------------------------------------------
+// (defined with the select kernels below)
+template <int METRIC, bool RESCORE, int NT>
+__device__ __forceinline__ void
+select_final_body(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows,
+                  uint32_t d, uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
+                  SearchCtl* __restrict__ ctl, uint32_t* __restrict__ hist,
+                  const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
+                  const uint32_t* __restrict__ wmax, uint32_t* __restrict__ out_rows,
+                  float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
+                  uint32_t* __restrict__ out_status, uint32_t* __restrict__ events,
+                  const unsigned long long* __restrict__ wbest, uint32_t epoch,
+                  unsigned long long* sk, uint32_t* hit, uint32_t* sh, uint32_t* cnt);
+
 template <int METRIC, int EX_CW /* chunk width in floats: 32 or 64 */, bool NT, int WPB /* waves per workgroup */,
-          bool ROLL /* refill load by load instead of chunk by chunk */>
+          bool ROLL /* refill load by load instead of chunk by chunk */,
+          bool FUSE = false /* workgroup 0 runs the one-workgroup select of the handle's PREVIOUS query */>
 __global__ void __launch_bounds__(WPB * 64)
 scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__ q,
                      const uint32_t* __restrict__ dead, uint32_t n_rows, uint32_t d,
                      uint32_t need, uint32_t k, const float* __restrict__ vmax_sq,
                      SearchCtl* __restrict__ ctl, uint32_t* __restrict__ keys,
                      uint32_t* __restrict__ tmax, uint32_t* __restrict__ wmax,
-                     uint32_t* __restrict__ hist, unsigned long long* __restrict__ wbest, uint32_t epoch) {
+                     uint32_t* __restrict__ hist, unsigned long long* __restrict__ wbest, uint32_t epoch,
+                     PrevSelect ps) {
     constexpr int EX_STRIDE = EX_CW + 4;  // padded LDS row stride in floats
     constexpr int LPR = EX_CW / 4;        // lanes that cover one row's chunk with 16-byte loads
     constexpr int RPL = 64 / LPR;         // rows covered by one wave-wide load
@@ -92,19 +107,41 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
     __shared__ uint32_t lhist[HIST_BINS];
     __shared__ float na_sh;
     __shared__ uint32_t keep_lds;   // sparse key stores: the bound wave 0 of the workgroup last computed
+    // FUSE: one launch = this query's scan + the previous query's select. The select is one workgroup's
+    // work of some 20 us, during which the rest of the device would idle if it ran as a kernel of its
+    // own behind the scan; here it is workgroup 0 of the NEXT scan's launch (the scan's workgroups are
+    // 1 .. gridDim.x - 1), reads the other scratch set, and costs the stream nothing: no second launch,
+    // no event, no second stream. Its candidate buffer lies over the tile images (a workgroup is one
+    // or the other).
+    uint32_t bid = blockIdx.x, nblk = gridDim.x;
+    if (FUSE) {
+        __shared__ uint32_t sel_hit[FUSE ? CAND_CAP : 1];
+        __shared__ uint32_t sel_sh[FUSE ? 24 : 1], sel_cnt[FUSE ? 4 : 1];
+        static_assert(!FUSE || sizeof(tiles) >= CAND_CAP * sizeof(unsigned long long), "candidate keys fit the tile images");
+        if (blockIdx.x == 0) {
+            select_final_body<METRIC, false, WPB * 64>(nullptr, ps.q, ps.n_rows, ps.d, ps.live, ps.need, ps.k, ps.n_waves,
+                                                       ps.ctl, ps.hist, ps.keys, ps.tmax, ps.wmax, ps.out_rows,
+                                                       ps.out_scores, ps.out_n, ps.out_status, ps.events, ps.wbest,
+                                                       ps.epoch, reinterpret_cast<unsigned long long*>(&tiles[0][0]),
+                                                       sel_hit, sel_sh, sel_cnt);
+            return;
+        }
+        bid -= 1u;
+        nblk -= 1u;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) keep_lds = 0u;
     for (int i = tid; i < (int)HIST_BINS; i += WPB * 64) lhist[i] = 0u;
 
     float* tile = tiles[wid];
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
-    const uint32_t n_waves = gridDim.x * (uint32_t)WPB;
+    const uint32_t n_waves = nblk * (uint32_t)WPB;
     const uint32_t d4 = d >> 2;
     const uint32_t n_chunks = (d + EX_CW - 1) / EX_CW;
     const int lrow = lane / LPR;  // row of a load within its group of RPL
     const int lcol = lane % LPR;  // float4 column within the chunk
 
-    uint32_t t = blockIdx.x * (uint32_t)WPB + wid;
+    uint32_t t = bid * (uint32_t)WPB + wid;
     v4f pre[NLD];
     {
         // issue the loads of chunk c of tile tt
@@ -121,17 +158,17 @@ scan_exact_v4_kernel(const float* __restrict__ corpus, const float* __restrict__
         // ||q|| while the first loads are in flight: one wave per workgroup runs
         // the sequential sum (cosine needs it in every workgroup; for the other
         // metrics only the copy published for the final stage is used)
-        if (wid == 0 && (METRIC == 0 || blockIdx.x == 0)) {
+        if (wid == 0 && (METRIC == 0 || bid == 0)) {
             const float nsq = query_norm_sq_wave(q, d, lane);
             if (lane == 0) {
                 na_sh = sqrtf(nsq);
-                if (blockIdx.x == 0) publish_ctl(ctl, nsq, need, k, vmax_sq, n_waves);
+                if (bid == 0) publish_ctl(ctl, nsq, need, k, vmax_sq, n_waves);
             }
         }
         __syncthreads();  // also covers the histogram zeroing above
         const float na = METRIC == 0 ? na_sh : 0.0f;
         uint32_t wave_best = 0u;  // largest key over all tiles of this wave
-        const uint32_t wave_id = blockIdx.x * (uint32_t)WPB + wid;
+        const uint32_t wave_id = bid * (uint32_t)WPB + wid;
         // sparse key stores (trag_scan_common.h): exact keys, so the bound is the need-th
         // largest published key itself
         const bool track = epoch != 0u && need >= 1u && need <= 64u && n_waves <= SPARSE_WAVES;
@@ -946,6 +983,7 @@ final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint
 // (Asking for ALL tile maxima at the kernel's start, beside the histogram -- 20 per thread at 1.25 M
 // rows -- and so skipping the level of the wave maxima measured no gain: 17.2 against 16.9 us.)
 // ---------------------------------------------------------------------------
+template <int NT /* threads of the workgroup */>
 __device__ __forceinline__ void gather_flat(uint32_t lo, uint32_t hi, bool rows_only, uint32_t n_rows,
                                             uint32_t n_tiles, uint32_t n_waves, uint32_t my_wmax,
                                             const uint32_t* __restrict__ wmax, const uint32_t* __restrict__ tmax,
@@ -953,7 +991,7 @@ __device__ __forceinline__ void gather_flat(uint32_t lo, uint32_t hi, bool rows_
                                             uint32_t* hit, uint32_t* n_hit, uint32_t* n_thit, uint32_t* n_cand) {
     const uint32_t tid = threadIdx.x;
     uint32_t* thit = reinterpret_cast<uint32_t*>(sk + CAND_CAP / 2);  // CAND_CAP words
-    for (uint32_t w0 = 0; w0 < n_waves; w0 += 1024u) {
+    for (uint32_t w0 = 0; w0 < n_waves; w0 += (uint32_t)NT) {
         const uint32_t w = w0 + tid;
         const uint32_t wm = w0 == 0 ? my_wmax : ((w < n_waves && w < n_tiles) ? wmax[w] : 0u);
         if (wm >= lo) {
@@ -965,11 +1003,11 @@ __device__ __forceinline__ void gather_flat(uint32_t lo, uint32_t hi, bool rows_
     const uint32_t nh = *n_hit < CAND_CAP ? *n_hit : CAND_CAP;
     const uint32_t tpw = (n_tiles + n_waves - 1u) / n_waves;  // tiles per scan wave
     const uint32_t total = nh * tpw;
-    for (uint32_t i0 = 0; i0 < total; i0 += 4096u) {
+    for (uint32_t i0 = 0; i0 < total; i0 += 4u * (uint32_t)NT) {
         uint32_t tile[4], tm[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t i = i0 + tid + 1024u * e;
+            const uint32_t i = i0 + tid + (uint32_t)NT * e;
             const uint32_t h = i / tpw, j = i - h * tpw;
             tile[e] = i < total ? hit[h] + j * n_waves : 0xFFFFFFFFu;
             tm[e] = tile[e] < n_tiles ? tmax[tile[e]] : 0u;
@@ -985,7 +1023,7 @@ __device__ __forceinline__ void gather_flat(uint32_t lo, uint32_t hi, bool rows_
     __syncthreads();
     const uint32_t nt = *n_thit < CAND_CAP ? *n_thit : CAND_CAP;
     const uint32_t lane = tid & 63u;
-    for (uint32_t t0 = 0; t0 < nt; t0 += 64u) {  // 16 waves x 4 tiles per round
+    for (uint32_t t0 = 0; t0 < nt; t0 += (uint32_t)NT / 16u) {  // NT / 64 waves x 4 tiles per round
         uint32_t row[4], key[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1013,48 +1051,28 @@ __device__ __forceinline__ void gather_flat(uint32_t lo, uint32_t hi, bool rows_
 // accumulates into. When the bin is too crowded (clustered scores, big tie
 // groups) the status ST_NEED_REFINE asks the host for the multi-level pipeline.
 // ---------------------------------------------------------------------------
-template <int METRIC, bool RESCORE>
-__global__ void __launch_bounds__(1024)
-select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows,
-                    uint32_t d, uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
-                    SearchCtl* __restrict__ ctl, uint32_t* __restrict__ hist,
-                    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
-                    const uint32_t* __restrict__ wmax, uint32_t* __restrict__ out_rows,
-                    float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
-                    uint32_t* __restrict__ out_status, MultiStride ms, uint32_t out_stride,
-                    uint32_t* __restrict__ events, const unsigned long long* __restrict__ wbest,
-                    uint32_t epoch) {
-    // Every argument is asked for here, at the top: left alone, the compiler fetches each group of
-    // arguments just before its first use, and this kernel -- one workgroup, nothing to overlap with,
-    // behind a scan that left neither the argument block nor the code in any cache -- then pays a
-    // round trip to memory for each group in turn (four of them before the histogram is even read:
-    // 7.8 of the kernel's 19.6 us at 1 M rows).
-    asm volatile("" ::"s"(corpus), "s"(q), "s"(n_rows), "s"(d), "s"(live), "s"(need), "s"(k), "s"(n_waves), "s"(ctl),
-                 "s"(hist), "s"(keys), "s"(tmax), "s"(wmax));
-    asm volatile("" ::"s"(out_rows), "s"(out_scores), "s"(out_n), "s"(out_status), "s"(ms.zero_bytes), "s"(ms.keys),
-                 "s"(ms.tmax), "s"(ms.wmax), "s"(out_stride), "s"(events), "s"(wbest), "s"(epoch));
-    // one workgroup per query of a multi-query scan (blockIdx.x = query; strides 0 for one query)
-    {
-        const size_t b = blockIdx.x;
-        q += b * d;
-        ctl = reinterpret_cast<SearchCtl*>(reinterpret_cast<char*>(ctl) + b * ms.zero_bytes);
-        hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + b * ms.zero_bytes);
-        keys += b * ms.keys;
-        tmax += b * ms.tmax;
-        wmax += b * ms.wmax;
-        out_rows += b * out_stride;
-        out_scores += b * out_stride;
-        out_n += b;
-        if (out_status) out_status += b;
-    }
-    __shared__ unsigned long long sk[CAND_CAP];
-    __shared__ uint32_t hit[CAND_CAP];
-    __shared__ uint32_t sh[24];
-    __shared__ uint32_t n_hit_sh, n_cand_sh, n_thit_sh, keep_sh;
+// The body, for a workgroup of NT threads (1024: the stand-alone kernel; 256: the workgroup that a fused
+// scan launch sets aside for the PREVIOUS query's select). LDS comes from the caller: sk[CAND_CAP],
+// hit[CAND_CAP], sh[24], cnt[4].
+template <int METRIC, bool RESCORE, int NT>
+__device__ __forceinline__ void
+select_final_body(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows,
+                  uint32_t d, uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
+                  SearchCtl* __restrict__ ctl, uint32_t* __restrict__ hist,
+                  const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
+                  const uint32_t* __restrict__ wmax, uint32_t* __restrict__ out_rows,
+                  float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
+                  uint32_t* __restrict__ out_status, uint32_t* __restrict__ events,
+                  const unsigned long long* __restrict__ wbest, uint32_t epoch,
+                  unsigned long long* sk, uint32_t* hit, uint32_t* sh, uint32_t* cnt) {
+    uint32_t& n_hit_sh = cnt[0];
+    uint32_t& n_cand_sh = cnt[1];
+    uint32_t& n_thit_sh = cnt[2];
+    uint32_t& keep_sh = cnt[3];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const uint32_t n_tiles = (n_rows + 63u) >> 6;
     // independent of the threshold: this thread's share of the per-wave maxima
-    const uint32_t my_wmax = ((uint32_t)tid < n_waves && (uint32_t)tid < n_tiles) ? wmax[tid] : 0u;
+    const uint32_t my_wmax = ((uint32_t)tid < n_waves && (uint32_t)tid < n_tiles) ? wmax[tid] : 0u;   // (waves 0 .. NT - 1)
     float na = 0.0f;
     if (RESCORE) na = ctl->na;
     // A scan with sparse key stores (trag_scan_common.h; single exact queries only) kept the keys
@@ -1072,7 +1090,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
     }
     uint32_t b1, above1;
     uint32_t inbin1;
-    find_bin<1024>(hist, need, b1, above1, sh, &inbin1);
+    find_bin<NT>(hist, need, b1, above1, sh, &inbin1);
     const uint32_t expect = above1 + inbin1;
     uint32_t status = ST_OK, n_out = 0, C = 0;
     // A crowded coarse bin (clustered scores: Euclidean distances between normalised vectors, big tie
@@ -1091,11 +1109,11 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         const uint32_t t_key = max(b1 << 21, keep_sh);
         const uint32_t t_min = t_key > 1u ? t_key : 1u;  // key 0 marks removed rows
         if (expect <= CAND_CAP / 2 || by_bound) {
-            gather_flat(t_min, 0xFFFFFFFFu, RESCORE, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit,
+            gather_flat<NT>(t_min, 0xFFFFFFFFu, RESCORE, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit,
                         &n_hit_sh, &n_thit_sh, &n_cand_sh);
         } else {
         // (more rows than the flat form holds) scan waves whose best key reaches the threshold ...
-        for (uint32_t w0 = 0; w0 < n_waves; w0 += 1024u) {
+        for (uint32_t w0 = 0; w0 < n_waves; w0 += (uint32_t)NT) {
             const uint32_t w = w0 + tid;
             const uint32_t wm = w0 == 0 ? my_wmax : ((w < n_waves && w < n_tiles) ? wmax[w] : 0u);
             if (wm >= t_min) {
@@ -1106,7 +1124,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         __syncthreads();
         const uint32_t nh = n_hit_sh < CAND_CAP ? n_hit_sh : CAND_CAP;
         // ... then their tiles (w, w + n_waves, ...), then the rows of the tiles that pass
-        for (uint32_t h = wid; h < nh; h += 16u) {
+        for (uint32_t h = wid; h < nh; h += (uint32_t)NT / 64u) {
             const uint32_t w = hit[h];
             for (uint32_t tb = 0; w + tb * n_waves < n_tiles; tb += 64u) {
                 const uint32_t tile = w + (tb + lane) * n_waves;
@@ -1178,6 +1196,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
             // tid % 256 against a quarter of the others per thread, two barriers -- instead of the 28
             // barriers of a 128-element sorting network (6.9 us of this kernel at 1 M rows)
             uint32_t* rank = hit;   // (the wave list is no longer needed)
+            constexpr uint32_t PARTS = NT / 256, SPAN = 256u / PARTS;
             const uint32_t i = (uint32_t)tid & 255u, part = (uint32_t)tid >> 8;
             if (RESCORE) {
                 __syncthreads();
@@ -1190,7 +1209,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
             __syncthreads();
             const unsigned long long mine = i < C ? sk[i] : 0ull;
             uint32_t above = 0u;
-            const uint32_t j0 = part * 64u, j1 = min(j0 + 64u, C);
+            const uint32_t j0 = part * SPAN, j1 = min(j0 + SPAN, C);
             for (uint32_t j = j0; j < j1; ++j) above += sk[j] > mine ? 1u : 0u;
             if (above) atomicAdd(&rank[i], above);
             __syncthreads();
@@ -1209,7 +1228,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         } else {
             uint32_t P = 128;
             while (P < C) P <<= 1;
-            for (uint32_t i = tid; i < P; i += 1024u) {
+            for (uint32_t i = tid; i < P; i += (uint32_t)NT) {
                 unsigned long long v = 0ull;
                 if (i < C) {
                     v = sk[i];
@@ -1223,7 +1242,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
             for (uint32_t size = 2; size <= P; size <<= 1) {
                 for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
                     __syncthreads();
-                    for (uint32_t i = tid; i < P / 2; i += 1024u) {
+                    for (uint32_t i = tid; i < P / 2; i += (uint32_t)NT) {
                         const uint32_t pos = 2 * i - (i & (stride - 1));
                         const unsigned long long a = sk[pos], b = sk[pos + stride];
                         const bool desc = (pos & size) == 0;
@@ -1232,7 +1251,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
                 }
             }
             __syncthreads();
-            for (uint32_t i = tid; i < n_out; i += 1024u) {
+            for (uint32_t i = tid; i < n_out; i += (uint32_t)NT) {
                 const unsigned long long v = sk[i];
                 out_rows[i] = 0xFFFFFFFFu - (uint32_t)(v & 0xFFFFFFFFull);
                 float sc = key_score((uint32_t)(v >> 32));
@@ -1244,7 +1263,7 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         if (RESCORE && tid == 0 && C < live && n_out > 0) status = certify<METRIC>(ctl, d, na, t_key, ek);
     }
     // leave the accumulator clean for the next query's scan
-    for (uint32_t i = tid; i < HIST_BINS; i += 1024u) hist[i] = 0u;
+    for (uint32_t i = tid; i < HIST_BINS; i += (uint32_t)NT) hist[i] = 0u;
     if (tid == 0) {
         *out_n = n_out;
         ctl->expect = C;
@@ -1256,6 +1275,50 @@ select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ 
         if (status == ST_NEED_REFINE && events)
             __hip_atomic_fetch_add(events, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+
+template <int METRIC, bool RESCORE>
+__global__ void __launch_bounds__(1024)
+select_final_kernel(const float* __restrict__ corpus, const float* __restrict__ q, uint32_t n_rows,
+                    uint32_t d, uint32_t live, uint32_t need, uint32_t k, uint32_t n_waves,
+                    SearchCtl* __restrict__ ctl, uint32_t* __restrict__ hist,
+                    const uint32_t* __restrict__ keys, const uint32_t* __restrict__ tmax,
+                    const uint32_t* __restrict__ wmax, uint32_t* __restrict__ out_rows,
+                    float* __restrict__ out_scores, uint32_t* __restrict__ out_n,
+                    uint32_t* __restrict__ out_status, MultiStride ms, uint32_t out_stride,
+                    uint32_t* __restrict__ events, const unsigned long long* __restrict__ wbest,
+                    uint32_t epoch) {
+    // Every argument is asked for here, at the top: left alone, the compiler fetches each group of
+    // arguments just before its first use, and this kernel -- one workgroup, nothing to overlap with,
+    // behind a scan that left neither the argument block nor the code in any cache -- then pays a
+    // round trip to memory for each group in turn (four of them before the histogram is even read:
+    // 7.8 of the kernel's 19.6 us at 1 M rows).
+    asm volatile("" ::"s"(corpus), "s"(q), "s"(n_rows), "s"(d), "s"(live), "s"(need), "s"(k), "s"(n_waves), "s"(ctl),
+                 "s"(hist), "s"(keys), "s"(tmax), "s"(wmax));
+    asm volatile("" ::"s"(out_rows), "s"(out_scores), "s"(out_n), "s"(out_status), "s"(ms.zero_bytes), "s"(ms.keys),
+                 "s"(ms.tmax), "s"(ms.wmax), "s"(out_stride), "s"(events), "s"(wbest), "s"(epoch));
+    // one workgroup per query of a multi-query scan (blockIdx.x = query; strides 0 for one query)
+    {
+        const size_t b = blockIdx.x;
+        q += b * d;
+        ctl = reinterpret_cast<SearchCtl*>(reinterpret_cast<char*>(ctl) + b * ms.zero_bytes);
+        hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hist) + b * ms.zero_bytes);
+        keys += b * ms.keys;
+        tmax += b * ms.tmax;
+        wmax += b * ms.wmax;
+        out_rows += b * out_stride;
+        out_scores += b * out_stride;
+        out_n += b;
+        if (out_status) out_status += b;
+    }
+    __shared__ unsigned long long sk[CAND_CAP];
+    __shared__ uint32_t hit[CAND_CAP];
+    __shared__ uint32_t sh[24];
+    __shared__ uint32_t cnt[4];
+    select_final_body<METRIC, RESCORE, 1024>(corpus, q, n_rows, d, live, need, k, n_waves, ctl, hist, keys, tmax, wmax,
+                                             out_rows, out_scores, out_n, out_status, events, wbest, epoch, sk, hit, sh,
+                                             cnt);
 }
 
 // ---------------------------------------------------------------------------
@@ -1399,7 +1462,7 @@ select_mirror_kernel(uint32_t n_rows, uint32_t d, uint32_t live, uint32_t need, 
     // maxima of the waves that pass, then the keys of the tiles that pass)
     auto gather = [&](uint32_t lo, uint32_t hi, uint32_t at_most) {
         if (at_most <= CAND_CAP / 2) {  // at_most: bound of the candidate count after this call
-            gather_flat(lo, hi, false, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit, &n_hit_sh,
+            gather_flat<1024>(lo, hi, false, n_rows, n_tiles, n_waves, my_wmax, wmax, tmax, keys, sk, hit, &n_hit_sh,
                         &n_thit_sh, &n_cand_sh);
             return;
         }
@@ -1872,7 +1935,7 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
 
 template <int METRIC>
 static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                                    uint32_t k, const float* d_vmax_sq, hipStream_t st) {
+                                    uint32_t k, const float* d_vmax_sq, hipStream_t st, const PrevSelect* prev) {
     if ((a.dim & 3u) == 0u) {
         const uint32_t n_tiles = (a.n_rows + 63u) / 64u;
         // One workgroup of 4 waves per CU, each wave with one 8 KB chunk in flight,
@@ -1912,14 +1975,24 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
         const uint32_t ep = (s.wbest && sparse_scan_pays(n_tiles, grid * 4u)) ? s.epoch : 0u;
         // load-by-load refill pays only for short rows (same run, MI355X: d = 128 +6 %, 384 -2 %,
         // 768 / 1536 / 4096 within noise)
-        if (a.dim <= 256)
+        const PrevSelect none{};
+        if (prev) {   // one more workgroup, in front: the previous query's select
+            if (a.dim <= 256)
+                hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, true, true>), dim3(grid + 1u), dim3(256), 0,
+                                   st, a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
+                                   s.tmax, s.wmax, s.hist, s.wbest, ep, *prev);
+            else
+                hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, false, true>), dim3(grid + 1u), dim3(256), 0,
+                                   st, a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
+                                   s.tmax, s.wmax, s.hist, s.wbest, ep, *prev);
+        } else if (a.dim <= 256)
             hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, true>), dim3(grid), dim3(256), 0, st,
                                a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
-                               s.tmax, s.wmax, s.hist, s.wbest, ep);
+                               s.tmax, s.wmax, s.hist, s.wbest, ep, none);
         else
             hipLaunchKernelGGL((scan_exact_v4_kernel<METRIC, 32, true, 4, false>), dim3(grid), dim3(256), 0, st,
                                a.corpus, d_q, a.dead, a.n_rows, a.dim, need, k, d_vmax_sq, s.ctl, s.keys,
-                               s.tmax, s.wmax, s.hist, s.wbest, ep);
+                               s.tmax, s.wmax, s.hist, s.wbest, ep, none);
         return grid * 4u;
     } else {
         const uint32_t grid = grid_for(a.n_rows, 256, 256 * 8);
@@ -1929,12 +2002,17 @@ static uint32_t scan_exact_dispatch(const float* d_q, const ScanArgs& a, const S
     }
 }
 
+// prev (optional; rows of 4 k components only -- scan_can_fuse): the select of the handle's previous
+// query rides in this launch (see scan_exact_v4_kernel, FUSE).
+bool scan_can_fuse(uint32_t dim) { return (dim & 3u) == 0u; }
+
 hipError_t launch_scan_exact(const float* d_q, const ScanArgs& a, const Scratch& s, uint32_t need,
-                             uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st) {
+                             uint32_t k, const float* d_vmax_sq, uint32_t* n_waves, hipStream_t st,
+                             const PrevSelect* prev) {
     switch (a.metric) {
-    case TRAG_COSINE: *n_waves = scan_exact_dispatch<0>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    case TRAG_EUCLIDEAN: *n_waves = scan_exact_dispatch<1>(d_q, a, s, need, k, d_vmax_sq, st); break;
-    default: *n_waves = scan_exact_dispatch<2>(d_q, a, s, need, k, d_vmax_sq, st); break;
+    case TRAG_COSINE: *n_waves = scan_exact_dispatch<0>(d_q, a, s, need, k, d_vmax_sq, st, prev); break;
+    case TRAG_EUCLIDEAN: *n_waves = scan_exact_dispatch<1>(d_q, a, s, need, k, d_vmax_sq, st, prev); break;
+    default: *n_waves = scan_exact_dispatch<2>(d_q, a, s, need, k, d_vmax_sq, st, prev); break;
     }
     return hipGetLastError();
 }

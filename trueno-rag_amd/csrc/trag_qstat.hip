@@ -58,6 +58,13 @@
 #define QS_ASM_LOADS 1
 #endif
 
+#ifndef QS_DMA
+#define QS_DMA 1
+#endif
+#ifndef QS_DMA_SCHED
+#define QS_DMA_SCHED 0
+#endif
+
 namespace trag {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -112,8 +119,17 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                uint32_t* __restrict__ dyn_cnt) {
     constexpr int D = KS * 16;
     constexpr int NT = 64 * NW;
+    // DMA (mirror only): the subtile's 16-byte pieces go from memory straight into LDS
+    // (global_load_lds_dwordx4: a wave-instruction fills 1 KB of consecutive LDS), no staging registers,
+    // no LDS write instructions. The image keeps its padded rows: a lane fetches whatever belongs at
+    // the LDS position it fills (lanes that fill padding fetch the block's first bytes).
+    constexpr bool DMA = MIR && (QS_DMA != 0);
     constexpr int STRIDE = D / 2 + 4;          // dwords per image row: the 4 spare dwords keep the 16-byte
                                                // fragment reads of 16 different rows on different banks
+    constexpr int IMG_SLOTS = 32 * STRIDE / 4;                 // 16-byte slots of an image
+    constexpr int NWI = (IMG_SLOTS + 63) / 64;                 // wave-instructions that fill one (DMA)
+    constexpr int NLD = (NWI + NW - 1) / NW;                   // ... per wave, at most
+    constexpr int IMG_DW = DMA ? NWI * 256 : 32 * STRIDE;      // dwords reserved per image
     constexpr int PE = MIR ? 8 : 4;            // corpus elements per 16-byte piece
     constexpr int PPR = D / PE;                // pieces per row
     constexpr int NSUB = RT / 32;              // subtiles per tile
@@ -126,7 +142,7 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
     constexpr int LOOK = 1 + (NSUB - 1 + DP) / NSUB;   // the furthest tile ahead a step loads from
     static_assert(32 * PPR % NT == 0 && RT % 32 == 0 && D % 128 == 0 && KS >= NF && KS % NL == 0, "tile geometry");
     static_assert(NSUB % DP == 0 || DP == 2 * NSUB, "ring geometry");
-    __shared__ __attribute__((aligned(16))) uint32_t img[NSLOT][32 * STRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t img[NSLOT][IMG_DW];
     __shared__ __attribute__((aligned(8))) float rowc[NSLOT][32][2];   // per row: scale, shift (see below)
     __shared__ uint32_t hit_q[2][NW][MODE == 1 ? HITS : 1], hit_row[2][NW][MODE == 1 ? HITS : 1], hit_v[2][NW][MODE == 1 ? HITS : 1];
     __shared__ uint32_t hit_n[2][NW];   // entries in each list (written back by its wave at the end of every tile)
@@ -338,6 +354,41 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         if (i == 0) *reinterpret_cast<float2*>(&rowc[sl][tid & 31][0]) = pre_rc[k];   // (16 threads store the same pair: harmless)
     };
 
+    // DMA form: 16-byte slot i * NT + tid of a subtile's image comes from byte goff[i] of the subtile's
+    // block of memory; the 64 slots of one wave-instruction are 1 KB of consecutive LDS, whose start
+    // goes into M0. The rows' (scale, shift) pairs travel the same way (256 bytes, every wave asks for
+    // them: the same bytes to the same place).
+    uint32_t goff[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int p = i * NT + tid, row = p / (PPR + 1), c = p % (PPR + 1);
+        goff[i] = (row < 32 && c < PPR) ? (uint32_t)(row * (int)ROW_BYTES + c * 16) : 0u;
+    }
+    typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    [[maybe_unused]] const uint32_t img_lds = (uint32_t)(uintptr_t)(lds_u32)(&img[0][0]) + (uint32_t)wid_s * 1024u;
+    [[maybe_unused]] const uint32_t rowc_lds = (uint32_t)(uintptr_t)(lds_u32)(reinterpret_cast<uint32_t*>(&rowc[0][0][0]));
+    [[maybe_unused]] const uint32_t lane4 = (uint32_t)lane * 4u;
+    constexpr int NDMA = NSUB * (NLD + 1);     // transfers per wave and tile
+    // transfer j of the tile that starts at row `trow` into the images of half `hf`
+    auto dma_piece = [&](int j, uint32_t trow, int hf) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int sub = j / (NLD + 1), i = j % (NLD + 1);
+        const uint32_t row0 = trow + 32u * (uint32_t)sub;
+        if (i < NLD) {
+            if ((i + 1) * NW > NWI && i * NW + wid_s >= NWI) return;   // (the last round is a partial one)
+            const char* base = src + (size_t)row0 * ROW_BYTES;   // (uniform)
+            const uint32_t m = img_lds + (uint32_t)((hf * NSUB + sub) * IMG_DW * 4 + i * NT * 16);
+            if (NTL) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" :: "s"(m), "v"(goff[i]), "s"(base) : "memory");
+            else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m), "v"(goff[i]), "s"(base) : "memory");
+        } else {
+            const char* rb = reinterpret_cast<const char*>(rowc_g) + (size_t)row0 * 8u;
+            const uint32_t m = rowc_lds + (uint32_t)((hf * NSUB + sub) * 32 * 8);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" :: "s"(m), "v"(lane4), "s"(rb) : "memory");
+        }
+#endif
+    };
+
     bf16x8 fr[NF];     // the fragment ring
     auto frag = [&](int sl, int ks) __attribute__((always_inline)) {
         return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&img[sl][r * STRIDE + 4 * h + ks * 8]));
@@ -526,20 +577,26 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         const uint32_t u = next_unit();
         unit[t] = u == NO_UNIT ? 0u : u;
     }
+    if (DMA) {
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
-        const uint32_t row0 = unit[0] * rows_per_unit + 32u * (uint32_t)sub;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) issue_piece(0, i, row0);
+        for (int j = 0; j < NDMA; ++j) dma_piece(j, unit[0] * rows_per_unit, 0);
         drain_vmem();
+    } else {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) write_piece(0, i, sub, row0);
-    }
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const uint32_t row0 = unit[0] * rows_per_unit + 32u * (uint32_t)sub;
 #pragma unroll
-    for (int w = NSUB; w < NSUB + DP; ++w) {   // subtile w of the stream: tile w / NSUB, ring slot w % DP
+            for (int i = 0; i < NL; ++i) issue_piece(0, i, row0);
+            drain_vmem();
 #pragma unroll
-        for (int i = 0; i < NL; ++i)
-            issue_piece(w % DP, i, unit[w / NSUB] * rows_per_unit + 32u * (uint32_t)(w % NSUB));
+            for (int i = 0; i < NL; ++i) write_piece(0, i, sub, row0);
+        }
+#pragma unroll
+        for (int w = NSUB; w < NSUB + DP; ++w) {   // subtile w of the stream: tile w / NSUB, ring slot w % DP
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                issue_piece(w % DP, i, unit[w / NSUB] * rows_per_unit + 32u * (uint32_t)(w % NSUB));
+        }
     }
     __syncthreads();
 
@@ -627,7 +684,37 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
                     acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[qb][ks], fr[ks % NF], acc[qb], 0, 0, 0);
                 if (ks + NF < KS) fr[ks % NF] = frag(sl, ks + NF);
 #ifndef QS_EXP_NOSTAGE
-                if (ks % PER == PER - 1) {
+                if (DMA) {
+                    // the whole next tile is asked for during this tile's first step, a transfer every few
+                    // k-steps: each has the rest of the tile to land (waited for in front of the barrier)
+#if QS_DMA_SCHED == 1
+                    // staggered: even waves ask at even k-steps, odd waves at odd ones (the waves of a workgroup run
+                    // in step behind the barrier: asking at the same k-step, all eight queue up at the one
+                    // address unit of the CU)
+                    {
+                        const int u = sub * KS + ks;
+                        if (u / 2 < NDMA && (u & 1) == (wid_s & 1)) dma_piece(u / 2, unit[1] * rows_per_unit, half ^ 1);
+                    }
+#elif QS_DMA_SCHED == 2
+                    // all at once, at the top of the tile
+                    if (sub == 0 && ks == 0) {
+#pragma unroll
+                        for (int j = 0; j < NDMA; ++j) dma_piece(j, unit[1] * rows_per_unit, half ^ 1);
+                    }
+#elif QS_DMA_SCHED == 3
+                    // four classes of waves, one k-step apart
+                    {
+                        const int u = sub * KS + ks;
+                        if (u / 4 < NDMA && (u & 3) == (wid_s & 3)) dma_piece(u / 4, unit[1] * rows_per_unit, half ^ 1);
+                    }
+#else
+                    if (sub == 0) {
+#pragma unroll
+                        for (int j = 0; j < NDMA; ++j)
+                            if (ks == (j * KS) / NDMA) dma_piece(j, unit[1] * rows_per_unit, half ^ 1);
+                    }
+#endif
+                } else if (ks % PER == PER - 1) {
                     write_piece(ring, ks / PER, wsl, row0_write);
                     issue_piece(ring, ks / PER, row0_issue);
                 }
@@ -688,6 +775,7 @@ qs_gemm_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ mi
         }
 #elif defined(QS_EXP_NOBAR)
 #else
+        if (DMA) drain_vmem();   // (the next tile's transfers have landed)
         __syncthreads();
 #endif
     };

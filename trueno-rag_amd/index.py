@@ -230,10 +230,11 @@ class VectorStore:
             C.c_void_p(d_scores_ptr), C.c_void_p(d_n_ptr), C.c_void_p(d_status_ptr) if d_status_ptr else None,
             C.c_void_p(stream) if stream else None), self._config.dimension, self._config.dimension)
 
-    def set_pipelined(self, enabled: bool) -> None:
+    def set_pipelined(self, enabled) -> None:
         """Single-query device-entry searches overlap their select with the next query's scan; outputs
-        are valid on a stream after fence(stream)."""
-        _abi.check(_abi.lib().trag_store_set_pipelined(self._h, 1 if enabled else 0))
+        are valid on a stream after fence(stream). 1 / True: the select runs on the handle's side
+        stream; 2: it rides as one more workgroup in the launch of the next query's scan."""
+        _abi.check(_abi.lib().trag_store_set_pipelined(self._h, int(enabled)))
 
     def fence(self, stream: int = 0) -> None:
         _abi.check(_abi.lib().trag_store_fence(self._h, C.c_void_p(stream) if stream else None))
