@@ -455,7 +455,7 @@ def main():
                        "entry": "host pointers (PCIe + synchronisation inside every step)" if args.host
                                 else "device-resident queries and results",
                        "pipelined": (("select of query i as one more workgroup of the launch of query i+1's scan; "
-                                      if pipe_mode == 2 else
+                                      if (pipe_mode == 2 or group is not None) else
                                       "select of query i on the handle's side stream beside the scan of query i+1; ")
                                      + "all results fenced inside the timed region") if pipelined else None,
                        "latency_us_per_call": 1e3 * ms_per_step if args.host else None,

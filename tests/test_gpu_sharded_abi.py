@@ -66,6 +66,70 @@ def test_shard_group_one_rank_runs_rccl(trag, oracle, overlap):
     store.close()
 
 
+@pytest.mark.parametrize("metric", [0, 1])
+def test_overlap_mode_single_queries_exchange_one_call_late(trag, oracle, metric):
+    """Overlap mode, one query per call: the local store defers each select into its next scan's launch,
+    and the group enqueues the exchange of call i when call i + 1 has been enqueued (or at the fence).
+    150 calls back to back, nothing synchronised (more than two laps of the 64-entry result ring, several
+    of its periodic waits), k changing from call to call, a 5-query call and a host-entry call in the
+    middle (both settle what is pending first), a second stream near the end: after one fence every
+    call's output holds the oracle's global rows and score bits."""
+    import torch
+    from trueno_rag_amd.sharded import ShardGroup
+    n, d, N = 120_000, 64, 150
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(metric), device=0,
+                                                    reserve_rows=n))
+    store.fill_synthetic(n, 41)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(42, 0, N, d)
+    dq = torch.from_numpy(Q).cuda()
+    g = ShardGroup(0, 1, 0, k_max=20, max_queries=8, overlap=True)
+    ks = [(3, 10, 20, 7)[i % 4] for i in range(N)]
+    kmax, row0 = 20, 5_000_000
+    rows = torch.full((N, kmax), -1, dtype=torch.int32, device="cuda")
+    scores = torch.zeros((N, kmax), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(N, dtype=torch.int32, device="cuda")
+    status = torch.full((N,), 9, dtype=torch.int32, device="cuda")
+    user, other = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    mid = {}
+    for i in range(N):
+        st = other if 140 <= i < 143 else user
+        if i == 70:      # a batch of 5 through the same group: queries 70..74 in one call
+            g.search_device(store, row0, 1, dq.data_ptr() + i * d * 4, 5, 10, rows.data_ptr() + i * kmax * 4,
+                            scores.data_ptr() + i * kmax * 4, cnt.data_ptr() + i * 4, status.data_ptr() + i * 4,
+                            st.cuda_stream)
+            continue
+        if 70 < i < 75:
+            continue
+        if i == 100:
+            mid["host"] = g.search_batch_rows(store, row0, 1, Q[100:101], 10)
+        g.search_device(store, row0, 1, dq.data_ptr() + i * d * 4, 1, ks[i], rows.data_ptr() + i * kmax * 4,
+                        scores.data_ptr() + i * kmax * 4, cnt.data_ptr() + i * 4, status.data_ptr() + i * 4,
+                        st.cuda_stream)
+    g.fence(user.cuda_stream)
+    user.synchronize()
+    torch.cuda.synchronize()
+    R, S, C, T = rows.cpu().numpy(), scores.cpu().numpy(), cnt.cpu().numpy(), status.cpu().numpy()
+    for i in range(N):
+        if 70 <= i < 75:
+            # (a batch call writes its outputs k apart: query b of the call at offset b * 10 of the call's block)
+            b = i - 70
+            flat_r = R[70:75].reshape(-1)[b * 10:(b + 1) * 10]
+            flat_s = S[70:75].reshape(-1)[b * 10:(b + 1) * 10]
+            er, es = oracle.search(corpus, Q[i], 10, metric)
+            assert_same_ranking(flat_r.astype(np.uint32), flat_s, er + row0, es, f"batch call, query {i}")
+            continue
+        k = ks[i]
+        er, es = oracle.search(corpus, Q[i], k, metric)
+        assert T[i] == 0 and C[i] == k, (i, T[i], C[i])
+        assert_same_ranking(R[i, :k].astype(np.uint32), S[i, :k], er + row0, es, f"call {i}")
+    er, es = oracle.search(corpus, Q[100], 10, metric)
+    assert_same_ranking(mid["host"][0][0], mid["host"][1][0], er + row0, es, "host entry in the middle")
+    g.close()
+    store.close()
+
+
 def _global_oracle(oracle, corpus, dead, q, k, metric):
     d8 = np.zeros(corpus.shape[0], dtype=np.uint8)
     d8[list(dead)] = 1

@@ -1339,6 +1339,11 @@ bool search_one_concurrent(trag_store* s, const float* query, uint32_t dim, uint
 
 }  // namespace
 
+bool trag::store_select_pending(trag_store* s) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    return s->has_pend;
+}
+
 extern "C" {
 
 trag_status trag_store_read_rows(const trag_store* s, uint64_t row0, uint64_t n, float* out) {

@@ -171,6 +171,10 @@ struct PrevSelect {
     uint32_t epoch = 0;
 };
 
+// Whether the handle holds a deferred select that no launch carries yet (trag_store_set_pipelined(s, 2):
+// the results of the last single query do not exist before the next scan's launch or a fence).
+bool store_select_pending(trag_store* s);
+
 // ---- kernel launchers (trag_kernels.hip) ----
 // the scans report the number of waves of their grid (tile t is scanned by wave t % n_waves)
 // prev (scan_can_fuse(dim) only): that select rides in the scan's launch as one more workgroup

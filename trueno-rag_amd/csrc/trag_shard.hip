@@ -176,10 +176,87 @@ struct trag_shard_group {
     ExchangeSlot slot[2];
     uint32_t next = 0;
     trag_store* piped = nullptr;    // the local store this group has switched to pipelined mode (overlap)
+    // Overlap mode, one query per call: the local store defers its selects (the select of call i rides
+    // in the launch of call i + 1's scan), so the records of call i exist only then -- and call i + 1
+    // (or trag_shard_fence, or any other call) enqueues call i's exchange on the side stream. The
+    // caller's stream then carries one launch and one event record per call. The local results go
+    // through a ring of small entries; every RING_WAIT calls the caller's stream waits for an exchange
+    // enqueued at least RING_WAIT calls earlier, which keeps an entry from being rewritten before the
+    // exchange that read it last has finished (the ring is four such periods long).
+    static constexpr uint32_t RING = 64, RING_WAIT = 16;
+    uint32_t* ring_rows = nullptr;
+    float* ring_scores = nullptr;
+    uint32_t* ring_n = nullptr;
+    uint32_t* ring_status = nullptr;
+    uint32_t* ring_pack = nullptr;       // (one each: the exchanges follow one another on the side stream)
+    uint32_t* ring_gathered = nullptr;
+    hipEvent_t ev_scan = nullptr, ev_done = nullptr, ev_mark[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t ring_calls = 0, ring_exchanged = 0;
+    struct PendingExchange {
+        bool on = false;
+        trag_store* local = nullptr;
+        uint32_t entry = 0, k = 0, row0 = 0, row_mul = 1;
+        uint32_t* out_rows = nullptr;
+        float* out_scores = nullptr;
+        uint32_t* out_n = nullptr;
+        uint32_t* status = nullptr;
+        hipStream_t st = nullptr;
+    } pend;
     uint32_t* h_pack = nullptr;     // pinned: records of the host entry, then its merged results
     size_t h_words = 0;
     std::mutex mu;
 };
+
+namespace {
+
+trag_status ring_alloc(trag_shard_group* g) {
+    if (g->ring_rows) return TRAG_OK;
+    const size_t km = g->cfg.k_max, R = trag_shard_group::RING;
+    SH_TRY(hipMalloc(&g->ring_rows, R * km * sizeof(uint32_t)));
+    SH_TRY(hipMalloc(&g->ring_scores, R * km * sizeof(float)));
+    SH_TRY(hipMalloc(&g->ring_n, R * sizeof(uint32_t)));
+    SH_TRY(hipMalloc(&g->ring_status, R * sizeof(uint32_t)));
+    SH_TRY(hipMalloc(&g->ring_pack, rec_words(g->cfg.k_max) * sizeof(uint32_t)));
+    SH_TRY(hipMalloc(&g->ring_gathered, (size_t)g->cfg.world * rec_words(g->cfg.k_max) * sizeof(uint32_t)));
+    SH_TRY(hipEventCreateWithFlags(&g->ev_scan, hipEventDisableTiming));
+    SH_TRY(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
+    for (hipEvent_t& e : g->ev_mark) SH_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return TRAG_OK;
+}
+
+// pack -> all-gather -> merge of one single-query call whose local results are in ring entry P.entry,
+// on the side stream (which the caller has ordered behind the select that wrote the entry)
+trag_status ring_exchange(trag_shard_group* g, const Rccl* R, const trag_shard_group::PendingExchange& P, bool local_ok) {
+    hipStream_t xs = g->side;
+    const size_t km = g->cfg.k_max, words = rec_words(P.k);
+    if (local_ok)
+        SH_TRY(launch_pack_topk(g->ring_rows + P.entry * km, g->ring_scores + P.entry * km, g->ring_n + P.entry, P.row0, 1, P.k,
+                                g->ring_pack, xs, P.row_mul ? P.row_mul : 1u, g->ring_status + P.entry));
+    else
+        SH_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g->ring_pack), (int)(ST_NEED_REFINE << 16), words, xs));
+    NCCL_TRY(R, R->AllGather(g->ring_pack, g->ring_gathered, words, ncclUint32, g->comm, xs));
+    SH_TRY(launch_merge_packed(g->ring_gathered, g->cfg.world, 1, P.k, P.out_rows, P.out_scores, P.out_n, xs, P.status));
+    SH_TRY(hipEventRecord(g->ev_done, xs));
+    const uint64_t e = g->ring_exchanged++;
+    if (e % trag_shard_group::RING_WAIT == trag_shard_group::RING_WAIT - 1)
+        SH_TRY(hipEventRecord(g->ev_mark[(e / trag_shard_group::RING_WAIT) % 4], xs));
+    return TRAG_OK;
+}
+
+// The exchange a deferred single-query call still owes: its select is launched (the local store's fence),
+// the side stream ordered behind it, the exchange enqueued.
+trag_status flush_pending_exchange(trag_shard_group* g, const Rccl* R) {
+    if (!g->pend.on) return TRAG_OK;
+    const trag_shard_group::PendingExchange P = g->pend;
+    g->pend.on = false;
+    trag_status ts = trag_store_fence(P.local, P.st);
+    if (ts != TRAG_OK) return ts;
+    SH_TRY(hipEventRecord(g->ev_scan, P.st));
+    SH_TRY(hipStreamWaitEvent(g->side, g->ev_scan, 0));
+    return ring_exchange(g, R, P, true);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -204,6 +281,12 @@ void trag_shard_group_destroy(trag_shard_group* g) {
         if (g->comm && rccl().handle) (void)rccl().CommDestroy(g->comm);
         slot_free(g->slot[0]);
         slot_free(g->slot[1]);
+        void* ring[] = {g->ring_rows, g->ring_scores, g->ring_n, g->ring_status, g->ring_pack, g->ring_gathered};
+        for (void* p : ring)
+            if (p) (void)hipFree(p);
+        hipEvent_t evs[] = {g->ev_scan, g->ev_done, g->ev_mark[0], g->ev_mark[1], g->ev_mark[2], g->ev_mark[3]};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
         if (g->h_pack) (void)hipHostFree(g->h_pack);
         if (g->side) (void)hipStreamDestroy(g->side);
     }
@@ -256,8 +339,15 @@ trag_status trag_shard_fence(trag_shard_group* g, void* hip_stream) {
     if (!g) return set_error(TRAG_INVALID_ARG, "null group");
     std::lock_guard<std::mutex> lk(g->mu);
     DeviceScope scope(g->device);
+    if (g->pend.on) {
+        const Rccl* R = nullptr;
+        trag_status ts = need_rccl(&R);
+        if (ts == TRAG_OK) ts = flush_pending_exchange(g, R);
+        if (ts != TRAG_OK) return ts;
+    }
     for (ExchangeSlot& sl : g->slot)
         if (sl.used) SH_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, sl.done, 0));
+    if (g->ring_exchanged) SH_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, g->ev_done, 0));
     return TRAG_OK;
 }
 
@@ -286,16 +376,70 @@ trag_status trag_shard_search_device(trag_shard_group* g, trag_store* local, uin
         if (d_status) SH_TRY(hipMemsetAsync(d_status, 0, n_queries * sizeof(uint32_t), st));
         return TRAG_OK;
     }
+    // overlap mode: the select of a single-query step leaves the critical path of the stream the scans
+    // run on (the local store defers it into its next scan's launch)
+    if (g->cfg.overlap && g->piped != local) {
+        trag_status tp = trag_store_set_pipelined(local, 2);
+        if (tp != TRAG_OK) return tp;
+        g->piped = local;
+    }
+    if (g->cfg.overlap && n_queries == 1) {
+        ts = ring_alloc(g);
+        if (ts != TRAG_OK) return ts;
+        const uint64_t c = g->ring_calls++;
+        constexpr uint64_t W = trag_shard_group::RING_WAIT;
+        if (c % W == 0 && c >= 2 * W) SH_TRY(hipStreamWaitEvent(st, g->ev_mark[(c / W - 2) % 4], 0));
+        trag_shard_group::PendingExchange me;
+        me.local = local;
+        me.entry = (uint32_t)(c % trag_shard_group::RING);
+        me.k = k;
+        me.row0 = row0;
+        me.row_mul = row_mul;
+        me.out_rows = d_out_rows;
+        me.out_scores = d_out_scores;
+        me.out_n = d_out_n;
+        me.status = d_status;
+        me.st = st;
+        const size_t km = g->cfg.k_max;
+        // (a pending exchange of another stream's call: settled first, so that this call's launch need not)
+        if (g->pend.on && (g->pend.st != st || g->pend.local != local)) {
+            ts = flush_pending_exchange(g, R);
+            if (ts != TRAG_OK) return ts;
+        }
+        const trag_status local_ts = trag_store_search_device(local, d_queries, 1, dim, k, g->ring_rows + me.entry * km,
+                                                              g->ring_scores + me.entry * km, g->ring_n + me.entry,
+                                                              g->ring_status + me.entry, st);
+        const std::string local_msg = local_ts != TRAG_OK ? std::string(trag_last_error()) : std::string();
+        if (local_ts != TRAG_OK && g->pend.on) (void)trag_store_fence(local, st);   // (the select the pending exchange waits for)
+        const bool deferred_now = local_ts == TRAG_OK && store_select_pending(local);
+        // whatever was pending before this call has its select on `st` by now: it rode in this call's
+        // launch, or the store launched it on its own
+        if (g->pend.on || !deferred_now) {
+            SH_TRY(hipEventRecord(g->ev_scan, st));
+            SH_TRY(hipStreamWaitEvent(g->side, g->ev_scan, 0));
+        }
+        if (g->pend.on) {
+            const trag_shard_group::PendingExchange P = g->pend;
+            g->pend.on = false;
+            ts = ring_exchange(g, R, P, true);
+            if (ts != TRAG_OK) return ts;
+        }
+        if (deferred_now) {
+            g->pend = me;
+            g->pend.on = true;
+            return TRAG_OK;
+        }
+        ts = ring_exchange(g, R, me, local_ts == TRAG_OK);
+        if (ts != TRAG_OK) return ts;
+        if (local_ts != TRAG_OK) return set_error(local_ts, "local search of this rank failed (the exchange was still joined): " + local_msg);
+        return TRAG_OK;
+    }
+    ts = flush_pending_exchange(g, R);
+    if (ts != TRAG_OK) return ts;
     ExchangeSlot& sl = g->slot[g->next];
     g->next ^= 1u;
     // the exchange that used this slot two calls ago may still be reading it on the side stream
     if (sl.used) SH_TRY(hipStreamWaitEvent(st, sl.done, 0));
-    // overlap mode: the select of a single-query step leaves the stream the scans run on as well
-    if (g->cfg.overlap && g->piped != local) {
-        trag_status tp = trag_store_set_pipelined(local, 1);
-        if (tp != TRAG_OK) return tp;
-        g->piped = local;
-    }
     // A rank whose local search cannot be enqueued still takes part in the collective -- its peers have
     // entered it or are about to, and an all-gather one rank never joins hangs them all: it sends
     // records that hold no row and carry status 3, so every rank sees the query as unfinished, and
@@ -360,8 +504,11 @@ trag_status trag_shard_search_batch(trag_shard_group* g, trag_store* local, uint
     if (row_mul == 0) row_mul = 1;
     std::lock_guard<std::mutex> lk(g->mu);
     DeviceScope scope(g->device);
+    ts = flush_pending_exchange(g, R);
+    if (ts != TRAG_OK) return ts;
     for (ExchangeSlot& sl : g->slot)
         if (sl.used) SH_TRY(hipEventSynchronize(sl.done));
+    if (g->ring_exchanged) SH_TRY(hipEventSynchronize(g->ev_done));
     ExchangeSlot& sl = g->slot[0];
     ExchangeSlot& res = g->slot[1];  // its result arrays receive the merged lists
     hipStream_t st = g->side;
