@@ -602,11 +602,13 @@ def mirror_leg(store, args, Q, out_rows, out_scores, out_n, status, n_local, d, 
 
     for i in range(args.warmup):
         step(i)
+    store.fence(sptr)
     torch.cuda.synchronize()
     store.set_profiling(4 if args.steps >= 40 else 1)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
+    store.fence(sptr)          # (a pipelined handle: the stages behind the last scans)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     scan_ms, launches = store.scan_time()

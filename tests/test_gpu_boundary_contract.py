@@ -183,19 +183,24 @@ def test_clone_is_an_independent_copy(trag, oracle):
     assert np.array_equal(rows, er) and store.len() == n - 3 and twin.len() == n - 3
 
 
+@pytest.mark.parametrize("mirror", [False, True])
 @pytest.mark.parametrize("pipe_mode", [1, 2])
 @pytest.mark.parametrize("metric", [0, 1])
-def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metric, pipe_mode):
+def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metric, pipe_mode, mirror):
     """Pipelined modes (trag_store_set_pipelined): the select of query i runs beside the scan of query
     i + 1 -- on the handle's side stream (1), or as one more workgroup of that scan's launch (2). 40
     single-query searches enqueued back to back on a user stream, a host-entry search and a batch in
     between (other routes: they wait for the pipeline), a second user stream; outputs are read only after
-    trag_store_fence -- all equal the oracle's."""
+    trag_store_fence -- all equal the oracle's. (mirror: the store holds a bf16 copy, single queries take
+    the scan of the copy, whose prune / exact scores / ordering go to the side stream in either mode; in the
+    middle of the run the copy is dropped, so exact-route queries follow mirror-route ones on the same sets.)"""
     import torch
     n, d, k, B = 1_500_000, 64, 10, 40
     store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(metric), device=0,
                                                     reserve_rows=n))
     store.fill_synthetic(n, 171)
+    if mirror:
+        store.set_bf16_mirror(True)
     corpus = store.read_rows(0, n)
     Q = oracle.synth_rows(172, 0, B, d)
     dq = torch.from_numpy(Q).cuda()
@@ -215,6 +220,8 @@ def test_pipelined_searches_equal_the_oracle_after_the_fence(trag, oracle, metri
             host[9] = store.search_rows(Q[9], k)        # host entry: not pipelined, waits for the pipeline
         if b == 25:
             host["batch"] = store.search_batch_rows(Q[:12], k)
+        if b == 30 and mirror:
+            store.set_bf16_mirror(False)
     # results may be read on a stream only behind the fence
     store.fence(user.cuda_stream)
     out = torch.empty_like(rows)

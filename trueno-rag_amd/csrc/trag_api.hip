@@ -675,9 +675,12 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     // Pipelined form (device entry of a handle that asked for it, one exact-order query, the
     // one-workgroup select): every other route runs on `st` alone, behind whatever the pipeline still
     // has on the side stream.
-    const bool pipe = may_pipeline && ((s->pipelined && s->side) || s->deferred) && n_queries == 1 &&
-                      mode == TRAG_SCAN_EXACT && !full_select && !(k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP);
-    if (!pipe && (s->pipe_used[0] || s->pipe_used[1] || s->has_pend)) {
+    const bool pipe_any = may_pipeline && ((s->pipelined && s->side) || s->deferred) && n_queries == 1 && !full_select &&
+                          !(k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP);
+    const bool pipe = pipe_any && mode == TRAG_SCAN_EXACT;
+    // (the mirror scan's three small stages always go to the side stream: they are launches of their own)
+    const bool pipe_mirror = pipe_any && mode == TRAG_SCAN_MIRROR && s->side && s->d_mirror;
+    if (!pipe && !pipe_mirror && (s->pipe_used[0] || s->pipe_used[1] || s->has_pend)) {
         ts = drain_pipeline(s, st);
         if (ts != TRAG_OK) return ts;
     }
@@ -756,6 +759,34 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
         const uint32_t need_m = full_select ? k_eff
                                                : (uint32_t)std::min<uint64_t>((uint64_t)k_eff + STREAM_SLACK, live);
         ScanArgs a{s->d_rows, s->d_dead, (uint32_t)s->n_rows, s->cfg.dim, s->cfg.metric};
+        if (pipe_mirror) {
+            // scan of the mirror on the caller's stream; prune, exact scores and ordering on the side stream
+            // beside the NEXT query's scan (two scratch sets; the query must stay valid until the fence)
+            const uint32_t x = s->pipe_next;
+            s->pipe_next ^= 1u;
+            Scratch& sc = x ? s->scratch2 : s->scratch;
+            if (s->has_pend) {   // (a deferred select of the exact route: launched now, ahead of this scan)
+                ts = s->pend_stream == st ? flush_pending(s) : drain_pipeline(s, st);
+                if (ts != TRAG_OK) return ts;
+            }
+            if (s->pipe_used[x]) HIP_TRY(hipStreamWaitEvent(st, s->sel_done[x], 0));
+            hipEvent_t e1 = nullptr;
+            HIP_TRY(scan_timer_begin(s, st, &e1));
+            uint32_t n_waves = 0;
+            s->last_ctl = sc.ctl;
+            HIP_TRY(next_scan_epoch(s, sc, true, st));
+            HIP_TRY(launch_scan_mirror(s->d_mirror, d_queries, s->d_norm2, a, sc, need_m, k_eff, s->d_vmax_sq, &n_waves, st));
+            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(hipEventRecord(s->scan_done[x], st));
+            HIP_TRY(hipStreamWaitEvent(s->side, s->scan_done[x], 0));
+            s->one_wg_queries += 1;
+            HIP_TRY(launch_select_mirror(d_queries, a, sc, false, live, need_m, k_eff, n_waves, d_out_rows, d_out_scores,
+                                         d_out_n, d_status, s->side));
+            HIP_TRY(hipEventRecord(s->sel_done[x], s->side));
+            s->pipe_used[x] = true;
+            s->stats.mode_used = mode;
+            return TRAG_OK;
+        }
         for (uint32_t b = 0; b < n_queries; ++b) {
             const float* q = d_queries + (size_t)b * s->cfg.dim;
             hipEvent_t e1 = nullptr;
@@ -824,6 +855,10 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
                 // by now --, or a scan form without the extra workgroup)
                 ts = drain_pipeline(s, st);
                 if (ts != TRAG_OK) return ts;
+            }
+            if (s->pipe_used[x]) {   // (a mirror-scan query's stages on the side stream used this set last)
+                HIP_TRY(hipStreamWaitEvent(st, s->sel_done[x], 0));
+                s->pipe_used[x] = false;
             }
             s->last_ctl = sc.ctl;
             HIP_TRY(next_scan_epoch(s, sc, true, st));
@@ -1390,7 +1425,7 @@ trag_status trag_store_set_pipelined(trag_store* s, int enabled) {
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
     if (enabled != 0 && enabled != 1 && enabled != 2) return fail(TRAG_INVALID_ARG, "pipelining mode must be 0, 1 or 2");
-    if (enabled == 1 && !s->side) {
+    if (enabled != 0 && !s->side) {
         HIP_TRY(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
         for (int x = 0; x < 2; ++x) {
             HIP_TRY(hipEventCreateWithFlags(&s->scan_done[x], hipEventDisableTiming));
@@ -1398,7 +1433,7 @@ trag_status trag_store_set_pipelined(trag_store* s, int enabled) {
         }
     }
     if (enabled == 2 && !s->pend_ev) HIP_TRY(hipEventCreateWithFlags(&s->pend_ev, hipEventDisableTiming));
-    if (enabled != 1 && s->side && (s->pipe_used[0] || s->pipe_used[1])) {
+    if (enabled == 0 && s->side && (s->pipe_used[0] || s->pipe_used[1])) {
         HIP_TRY(hipStreamSynchronize(s->side));   // (what was enqueued finishes; later calls run on one stream)
         s->pipe_used[0] = s->pipe_used[1] = false;
     }
