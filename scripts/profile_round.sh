@@ -26,6 +26,10 @@ run c2_1Mx384 fetch --rows 1000000 --steps 100
 run c3_1Mx768_b256 "fetch gemm" --rows 1000000 --dim 768 --batch 256 --steps 20
 run c3_1Mx768_b256_mirror "fetch gemm" --rows 1000000 --dim 768 --batch 256 --steps 20 --mirror
 run c4shard_1.25Mx384_b1 fetch --rows 1250000 --steps 100
+# the same single-query step with the exchange a sharded run adds (RCCL at world size 1: pack, all-gather, merge)
+export TRAG_BENCH_FORCE_EXCHANGE=1
+run c4shard_1.25Mx384_b1_exchange "" --rows 1250000 --steps 100
+unset TRAG_BENCH_FORCE_EXCHANGE
 run c4shard_1.25Mx384_b1000 "fetch gemm" --rows 1250000 --batch 1000 --steps 20
 run c4shard_1.25Mx384_b1000_mirror "fetch gemm" --rows 1250000 --batch 1000 --steps 20 --mirror
 run c4shard_1.25Mx384_b256 gemm --rows 1250000 --batch 256 --steps 20
