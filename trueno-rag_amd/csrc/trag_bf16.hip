@@ -261,7 +261,11 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int row = (wid * NB + i) * 8 + lrow;
+#ifdef BF_EXP_SAMETILE
+            const uint32_t r = (nts % 64u) * (uint32_t)BN + (uint32_t)row;   // (ablation: 8 tiles per XCD, L2-resident; results wrong)
+#else
             const uint32_t r = min(n0 + (uint32_t)row, n_rows - 1u);
+#endif
             bsrc[i] = mirror + (size_t)r * d + ((slot ^ ((row >> 1) & 7)) << 3);
         }
         typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -325,6 +329,9 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
         }
         // (The same staging for the 128 x 128 tile of 65..128 queries measured 12 % slower than its
         // register-staged form, so only the 256 x 256 tile uses it.)
+        // (Memory latency is not what this pass lacks either: with the corpus operand taken from a window of
+        // 8 tiles per XCD, resident in its L2 -- -DBF_EXP_SAMETILE, results wrong, timing only -- the full
+        // pass over 1 M x 768 x 256 queries takes 482 us against 504: deeper prefetch has 4 % to win.)
         // (A persistent form -- one workgroup per CU walking through its tiles, step 0 of the next
         // tile in flight during the epilogue -- measured 6 % slower: the extra live pointers spill.)
     } else {
