@@ -668,7 +668,10 @@ def pmc_traffic(args):
                 if r.get("Counter_Name") != "FETCH_SIZE":
                     continue
                 if ("scan_exact" in name or "scan_mirror" in name or "scan_stream" in name or "gemm_" in name):
-                    vals.setdefault(name.split("(")[0], []).append(float(r["Counter_Value"]))
+                    key = name.split("(")[0]
+                    if "scan_exact_v4" in key:   # (with and without the previous query's select aboard: one kernel)
+                        key = key.replace(", true>", ">").replace(", false>", ">")
+                    vals.setdefault(key, []).append(float(r["Counter_Value"]))
         if not vals:
             return None
         # the dominant scan kernel = the one that fetched most in total; drop its first launch (warm-up)
