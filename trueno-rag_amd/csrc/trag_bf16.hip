@@ -27,6 +27,16 @@
 #include "trag_device.h"
 #include "trag_internal.h"
 
+#ifndef BF_FRAG_SCHED
+#define BF_FRAG_SCHED 2
+#endif
+#ifndef BF_FRAG_SCHED_R
+#define BF_FRAG_SCHED_R 1
+#endif
+#ifndef BF_ASM_XFER
+#define BF_ASM_XFER 1
+#endif
+
 namespace trag {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -270,8 +280,44 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
         }
         typedef __attribute__((address_space(3))) void* lds_ptr;
         typedef const __attribute__((address_space(1))) void* glb_ptr;
+#if BF_ASM_XFER
+        // the same transfers by inline assembly: a scalar base per 8-row block and k-step plus one 32-bit
+        // lane offset fixed for the workgroup's life (no 64-bit vector address arithmetic per transfer), M0
+        // set beside it; the compiler does not know them as LDS writes, so nothing it reads from LDS waits
+        // for them -- the wait is explicit, in front of the step barrier
+        uint32_t voff_a[NA], voff_b[NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int row = (wid * NA + i) * 8 + lrow;
+            voff_a[i] = (uint32_t)lrow * d * 2u + (uint32_t)((slot ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = (wid * NB + i) * 8 + lrow;
+            const uint32_t r = min(n0 + (uint32_t)row, n_rows - 1u);
+            voff_b[i] = (r - n0) * d * 2u + (uint32_t)((slot ^ ((row >> 1) & 7)) << 4);
+        }
+        [[maybe_unused]] const char* const a_base = reinterpret_cast<const char*>(Qb) + (size_t)(q0 + (uint32_t)(wid * NA * 8)) * d * 2u;
+        [[maybe_unused]] const char* const b_base = reinterpret_cast<const char*>(mirror) + (size_t)n0 * d * 2u;
+        typedef __attribute__((address_space(3))) uint32_t* lds_u32 [[maybe_unused]];
+#endif
         auto transfer = [&](uint32_t* dst, uint32_t kt) __attribute__((always_inline)) {
             uint32_t* b_dst = dst + BM * 32;
+#if BF_ASM_XFER && defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t m_a = (uint32_t)(uintptr_t)(lds_u32)(dst) + (uint32_t)(wid * NA) * 1024u;
+            const uint32_t m_b = (uint32_t)(uintptr_t)(lds_u32)(b_dst) + (uint32_t)(wid * NB) * 1024u;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const char* sb = a_base + (size_t)(i * 8) * d * 2u + (size_t)kt * (BF_K * 2);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m_a + (uint32_t)i * 1024u), "v"(voff_a[i]), "s"(sb) : "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const char* sb = b_base + (size_t)kt * (BF_K * 2);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(m_b + (uint32_t)i * 1024u), "v"(voff_b[i]), "s"(sb) : "memory");
+            }
+            return;
+#endif
 #pragma unroll
             for (int i = 0; i < NA; ++i)
                 __builtin_amdgcn_global_load_lds((glb_ptr)(asrc[i] + (size_t)kt * BF_K),
@@ -288,7 +334,11 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
         // just issued (otherwise it waits for them before the first read and nothing overlaps).
         auto kstep = [&](const uint32_t* __restrict__ cur, uint32_t* __restrict__ nxt, bool more, uint32_t kt_next)
                          __attribute__((always_inline)) {
+#if !BF_ASM_XFER
+#ifndef BF_EXP_NOXFER   // (ablation: only the first step's transfers; results wrong)
             if (more) transfer(nxt, kt_next);
+#endif
+#endif
             const uint32_t* Bc = cur + BM * 32;
             // fragments ping-pong through two register sets: those of MFMA step ks + 1 are read
             // while the MFMAs of step ks run (the staging registers this path does not need pay for it)
@@ -305,8 +355,60 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                         &Bc[(wn * 64 + n * 32 + frow) * 32 + chunk]));
             };
             frags(0, 0);
+#if BF_ASM_XFER
+            // (the step's first fragment reads are on their way while the transfers are issued. Measured and
+            // not kept: the younger wave of each SIMD issuing its transfers in the middle of the step instead,
+            // so that the two never stage at once -- 476 us against 449: what it issues late lands late.)
+            if (more) transfer(nxt, kt_next);
+#endif
 #pragma unroll
             for (int ks = 0; ks < BF_K / 16; ++ks) {
+#if BF_FRAG_SCHED == 1
+                // the next step's fragment reads go out behind this step's first two MFMAs: the first MFMA of
+                // a k-step then waits for six reads, not twelve, and the others travel under MFMAs
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][0], fb[ks & 1][n], acc[0][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < BF_K / 16) frags((ks + 1) & 1, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 1; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#elif BF_FRAG_SCHED == 2
+                // ... and spread: two reads behind every pair of MFMAs, the corpus fragments first
+                {
+                    const int nb = (ks + 1) & 1;
+                    const bool more_k = ks + 1 < BF_K / 16;
+                    const int chunk = (((ks + 1) * 2 + half) ^ sw) << 2;
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) {
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more_k) {
+                            if (m == 0) {
+#pragma unroll
+                                for (int n = 0; n < 2; ++n)
+                                    fb[nb][n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                                        &Bc[(wn * 64 + n * 32 + frow) * 32 + chunk]));
+                            } else {
+                                // (TM query fragments over the TM - 1 remaining gaps)
+#pragma unroll
+                                for (int mm = 0; mm < TM; ++mm)
+                                    if ((mm * (TM - 1)) / TM == m - 1)
+                                        fa[nb][mm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                                            &cur[(wm * 32 * TM + mm * 32 + frow) * 32 + chunk]));
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#else
                 if (ks + 1 < BF_K / 16) frags((ks + 1) & 1, ks + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -315,18 +417,40 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                     for (int n = 0; n < 2; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         };
         transfer(lds0, 0u);
+#ifdef BF_EXP_NOBAR
+#define BF_STEP_BARRIER() ((void)0)   // (ablation: what the step barrier costs; results wrong)
+#elif BF_ASM_XFER
+#define BF_STEP_BARRIER() { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }   // (vmcnt(0): this wave's transfers)
+#else
+#define BF_STEP_BARRIER() __syncthreads()
+#endif
+#ifdef BF_STAMP
+        // (where a k-step's time goes: cycles spent waiting at the step barrier -- own transfers, then the
+        // other waves -- against the rest, per wave, printed by a few workgroups)
+        unsigned long long st_bar = 0, st_work = 0, st_t = __builtin_amdgcn_s_memtime(), st_0 = st_t;
+#define BF_STAMP_BAR() { const unsigned long long a_ = __builtin_amdgcn_s_memtime(); st_work += a_ - st_t; __builtin_amdgcn_s_waitcnt(0x0F70); const unsigned long long b0_ = __builtin_amdgcn_s_memtime(); st_vm += b0_ - a_; __syncthreads(); st_t = __builtin_amdgcn_s_memtime(); st_bar += st_t - b0_; }
+        unsigned long long st_vm = 0;
+#else
+#define BF_STAMP_BAR() BF_STEP_BARRIER()
+#endif
         for (uint32_t kt = 0; kt < nk; kt += 2) {
-            __syncthreads();  // this step's transfers have landed (every wave waited for its own before
-                              // the barrier) and every wave is done with the other stage
+            BF_STAMP_BAR();  // this step's transfers have landed (every wave waited for its own before
+                             // the barrier) and every wave is done with the other stage
             kstep(lds0, lds1, kt + 1u < nk, kt + 1u);
             if (kt + 1u < nk) {
-                __syncthreads();
+                BF_STAMP_BAR();
                 kstep(lds1, lds0, kt + 2u < nk, kt + 2u);
             }
         }
+#ifdef BF_STAMP
+        if (MODE == 1 && lane == 0 && (blockIdx.x % 997u) == 5u)
+            printf("blk %u wave %d ksteps %u work %llu vmwait %llu barrier %llu total %llu\n", blockIdx.x, wid, nk, st_work,
+                   st_vm, st_bar, (unsigned long long)__builtin_amdgcn_s_memtime() - st_0);
+#endif
         // (The same staging for the 128 x 128 tile of 65..128 queries measured 12 % slower than its
         // register-staged form, so only the 256 x 256 tile uses it.)
         // (Memory latency is not what this pass lacks either: with the corpus operand taken from a window of
@@ -400,6 +524,48 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
                 // register and exposes a full LDS latency before every second MFMA (measured:
                 // matrix pipe 21 % busy). Double-buffering the fragments in registers (reading those of
                 // step ks + 1 under the MFMAs of ks) measured slower: 256 queries x 1M x 768 0.75 -> 0.91 ms.
+#if BF_FRAG_SCHED_R == 1
+                // fragments ping-pong through two register sets, the reads of MFMA step ks + 1 spread behind
+                // the MFMAs of step ks (two reads per pair of MFMAs, the corpus fragments first)
+                if (TM == 4) {
+                    bf16x8 fa[2][TM], fb[2][2];
+                    auto rd_a = [&](int ks, int m) {
+                        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                            &As[(wm * 32 * TM + m * 32 + frow) * BF_LD + ks * 8 + half * 4]));
+                    };
+                    auto rd_b = [&](int ks, int n) {
+                        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                            &Bs[(wn * 64 + n * 32 + frow) * BF_LD + ks * 8 + half * 4]));
+                    };
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) fb[0][n] = rd_b(0, n);
+#pragma unroll
+                    for (int m = 0; m < TM; ++m) fa[0][m] = rd_a(0, m);
+#pragma unroll
+                    for (int ks = 0; ks < BF_K / 16; ++ks) {
+                        const int nb = (ks + 1) & 1;
+                        const bool more_k = ks + 1 < BF_K / 16;
+#pragma unroll
+                        for (int m = 0; m < TM; ++m) {
+#pragma unroll
+                            for (int n = 0; n < 2; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more_k) {
+                                if (m == 0) {
+#pragma unroll
+                                    for (int n = 0; n < 2; ++n) fb[nb][n] = rd_b(ks + 1, n);
+                                } else {
+#pragma unroll
+                                    for (int mm = 0; mm < TM; ++mm)
+                                        if ((mm * (TM - 1)) / TM == m - 1) fa[nb][mm] = rd_a(ks + 1, mm);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else
+#endif
 #pragma unroll
                 for (int ks = 0; ks < BF_K / 16; ++ks) {
                     bf16x8 fa[TM], fb[2];
