@@ -36,6 +36,9 @@
 #ifndef BF_ASM_XFER
 #define BF_ASM_XFER 1
 #endif
+#ifndef BF_PINGPONG
+#define BF_PINGPONG 0
+#endif
 
 namespace trag {
 
@@ -420,6 +423,107 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
 #endif
             }
         };
+#if BF_PINGPONG && BF_ASM_XFER
+        // An experiment, off by default (-DBF_PINGPONG=1): the two waves of a SIMD (w and w + NW / 2) take
+        // turns -- while one issues the MFMAs of half a k-step, the other reads the fragments of its next half
+        // from LDS; a workgroup barrier closes every phase, and the waves NW / 2 .. NW - 1 run one phase behind
+        // the others. What prompted it (stamps, -DBF_STAMP, 1 M x 768 x 256 queries): left to themselves the two
+        // run the same phases at the same times -- both wait for LDS, then both want the matrix pipe, which the
+        // older one gets: its 32 MFMAs take 1770 cycles of a k-step, the younger one finishes at 2800, and the
+        // older one waits for it at the barrier (14 000 of a workgroup's 38 000 cycles). Bit-identical results,
+        // but SLOWER: 491 us against 449 for the full pass, 50 000 cycles a workgroup. MFMAs are issued
+        // asynchronously, so a phase barrier does not mark the end of the multiplying, and a wave's next
+        // fragment reads wait for its own MFMAs in flight to release the registers; four barriers a k-step
+        // cost more than the alternation gains. (LDS is not the limit either: SQ_LDS_IDX_ACTIVE 17 % of the
+        // cycles, no bank conflicts.)
+        {
+            const bool grp1 = wid >= NW / 2;
+            bf16x8 fa[2][TM], fb[2][2];
+            auto rd = [&](const uint32_t* cur, int c) __attribute__((always_inline)) {   // MFMA steps 2 c and 2 c + 1
+                const uint32_t* Bc = cur + BM * 32;
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int chunk = (((2 * c + bb) * 2 + half) ^ sw) << 2;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        fb[bb][n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                            &Bc[(wn * 64 + n * 32 + frow) * 32 + chunk]));
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+                        fa[bb][m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(
+                            &cur[(wm * 32 * TM + m * 32 + frow) * 32 + chunk]));
+                }
+            };
+            auto mm = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[bb][m], fb[bb][n], acc[m][n], 0, 0, 0);
+            };
+            // (LDS only: the transfers in flight are waited for once per k-step, not at every phase)
+#define BF_PP_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define BF_PP_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+            static_assert(BF_K == 64, "two halves of two MFMA steps");
+            // Every wave runs the same four phases per k-step -- read half 0, multiply, read half 1, multiply --
+            // the second group one barrier behind the first. Transfers of step kt + 1 go into the stage that
+            // step kt - 1 was read from, free once the second group has read its second half: the first group
+            // issues them at the top of its step kt, the second group in the last phase of its step kt - 1 (the
+            // same moment), and each waits for its own three phases later, in front of the barrier behind which
+            // the first group starts to read them.
+#ifdef BF_STAMP
+            unsigned long long pp_t = __builtin_amdgcn_s_memtime(), pp_0 = pp_t, pp_rd = 0, pp_mm = 0, pp_vm = 0, pp_bar = 0;
+#define BF_PP_T(acc_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - pp_t; pp_t = n_; }
+#else
+#define BF_PP_T(acc_) ((void)0)
+#endif
+            auto step = [&](const uint32_t* cur, uint32_t* nxt, uint32_t kt) __attribute__((always_inline)) {
+                if (!grp1 && kt + 1u < nk) transfer(nxt, kt + 1u);
+                rd(cur, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                BF_PP_T(pp_rd);
+                BF_PP_BAR();
+                BF_PP_T(pp_bar);
+                mm();
+                BF_PP_T(pp_mm);
+                BF_PP_BAR();
+                BF_PP_T(pp_bar);
+                rd(cur, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                BF_PP_T(pp_rd);
+                if (grp1) BF_PP_VM();
+                BF_PP_T(pp_vm);
+                BF_PP_BAR();
+                BF_PP_T(pp_bar);
+                if (grp1 && kt + 2u < nk) transfer(const_cast<uint32_t*>(cur), kt + 2u);
+                mm();
+                BF_PP_T(pp_mm);
+                if (!grp1) BF_PP_VM();
+                BF_PP_T(pp_vm);
+                BF_PP_BAR();
+                BF_PP_T(pp_bar);
+            };
+            transfer(lds0, 0u);
+            BF_PP_VM();
+            BF_PP_BAR();
+            if (grp1) {
+                if (nk > 1u) transfer(lds1, 1u);
+                BF_PP_BAR();
+            }
+            for (uint32_t kt = 0; kt < nk; kt += 2) {
+                step(lds0, lds1, kt);
+                if (kt + 1u < nk) step(lds1, lds0, kt + 1u);
+            }
+            if (!grp1) BF_PP_BAR();
+#ifdef BF_STAMP
+            if (MODE == 1 && lane == 0 && (blockIdx.x % 997u) == 5u)
+                printf("blk %u wave %d ksteps %u read %llu mfma %llu vmwait %llu barrier %llu total %llu\n", blockIdx.x, wid, nk,
+                       pp_rd, pp_mm, pp_vm, pp_bar, (unsigned long long)__builtin_amdgcn_s_memtime() - pp_0);
+#endif
+        }
+#else
         transfer(lds0, 0u);
 #ifdef BF_EXP_NOBAR
 #define BF_STEP_BARRIER() ((void)0)   // (ablation: what the step barrier costs; results wrong)
@@ -451,6 +555,7 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
             printf("blk %u wave %d ksteps %u work %llu vmwait %llu barrier %llu total %llu\n", blockIdx.x, wid, nk, st_work,
                    st_vm, st_bar, (unsigned long long)__builtin_amdgcn_s_memtime() - st_0);
 #endif
+#endif   // BF_PINGPONG
         // (The same staging for the 128 x 128 tile of 65..128 queries measured 12 % slower than its
         // register-staged form, so only the 256 x 256 tile uses it.)
         // (Memory latency is not what this pass lacks either: with the corpus operand taken from a window of
@@ -509,14 +614,24 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
     for (int s = 0; s < PF; ++s)
         if ((uint32_t)s < nk) prefetch(s, (uint32_t)s);
 
+#ifdef BF_STAMP
+    unsigned long long sr_bar1 = 0, sr_stage = 0, sr_bar2 = 0, sr_rest = 0, sr_t = __builtin_amdgcn_s_memtime(), sr_0 = sr_t;
+#define BF_SR(acc_) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc_ += n_ - sr_t; sr_t = n_; }
+#else
+#define BF_SR(acc_) ((void)0)
+#endif
     for (uint32_t kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             const uint32_t kt = kt0 + (uint32_t)s;
             if (kt < nk) {  // uniform over the workgroup
+                BF_SR(sr_rest);
                 __syncthreads();
+                BF_SR(sr_bar1);
                 stage(s);
+                BF_SR(sr_stage);
                 __syncthreads();
+                BF_SR(sr_bar2);
                 // (issuing these loads before the barrier above measured 5 % slower)
                 if (kt + PF < nk) prefetch(s, kt + PF);
                 // All fragments of a k-step are read before its MFMAs start (scheduling barriers):
@@ -589,6 +704,12 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
         }
     }
 
+#ifdef BF_STAMP
+    BF_SR(sr_rest);
+    if (MODE == 1 && lane == 0 && (blockIdx.x % 997u) == 5u)
+        printf("blk %u wave %d ksteps %u barrier-in %llu stage %llu barrier-out %llu loads+mfma %llu total %llu\n", blockIdx.x,
+               wid, nk, sr_bar1, sr_stage, sr_bar2, sr_rest, (unsigned long long)__builtin_amdgcn_s_memtime() - sr_0);
+#endif
     }
 
     // ---- epilogue. v = the row-dependent part of the score, per accumulator:
