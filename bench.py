@@ -415,7 +415,9 @@ def main():
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_avg_ms > 0 else 0.0
         # corpus passes per step, from the library's own count of timed scans (the bf16 prefilter
         # takes up to 2048 queries a pass in its query-stationary form and 256 in its tiled form)
-        passes = 1 if args.hybrid else max(1, round(scan_launches * prof_every / max(args.steps, 1)))
+        # (one query a step is one pass whatever was timed: a handle with deferred selects reports every launch,
+        # timed in runs, not every prof_every-th)
+        passes = 1 if (args.hybrid or B == 1) else max(1, round(scan_launches * prof_every / max(args.steps, 1)))
         b_launch = B / passes                                   # queries served by one scan launch
         flops = 2.0 * b_launch * n_local * d
         tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
@@ -495,7 +497,11 @@ def main():
                                    "whole_step_GBps": algo_bytes / (ms_per_step * 1e-3) / 1e9,
                                    # a kernel cannot take longer than the step that contains it: if the event
                                    # brackets say so, they measured something else and `frac` is not evidence
-                                   "timing_inconsistent": bool(scan_avg_ms * passes > ms_per_step * 1.0005)})
+                                   "timing_inconsistent": bool(scan_avg_ms * passes > ms_per_step * 1.005)})
+        if pipe_mode == 2 and group is None and ex is None:
+            result["roofline"]["kernel_timed"] = ("event pairs around runs of 4 consecutive launches (a launch = this query's "
+                                                  "scan + the previous query's select as one more workgroup): a pair around "
+                                                  "a single launch opens a gap that the steps do not have")
         if args.hybrid:
             result["roofline"]["kernel_timed"] = ("the dense scan alone on the stream (no BM25 beside it), the last "
                                                   "steps' queries again after the timed region")

@@ -395,8 +395,11 @@ trag_status trag_store_set_scan_mode(trag_store *s, uint32_t scan_mode);
 /* Scan-kernel timing with HIP events on the stream the kernel runs on. While
  * enabled, every enabled-th scan launch (1 = every launch) is bracketed by an
  * event pair (at most 4096 are kept; an event pair costs about 6 us of stream
- * time, which matters for sub-millisecond scans). trag_store_scan_time waits for the recorded events, returns their
- * summed duration and count, and clears them. */
+ * time, which matters for sub-millisecond scans). On a handle with deferred selects
+ * (trag_store_set_pipelined mode 2) a step is one launch and the launches follow one another without
+ * a gap, which a pair around a single launch would open; there a pair spans a run of
+ * max(enabled, 4) consecutive launches and counts as that many. trag_store_scan_time waits for the
+ * recorded events, returns their summed duration and the number of launches they span, and clears them. */
 trag_status trag_store_set_profiling(trag_store *s, int enabled);
 trag_status trag_store_scan_time(trag_store *s, double *total_ms, uint32_t *launches);
 

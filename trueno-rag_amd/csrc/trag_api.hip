@@ -167,7 +167,14 @@ struct trag_store {
     uint32_t profile_every = 1;    // bracket every n-th scan launch with events
     uint32_t profile_seen = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;  // created once, reused
+    std::vector<uint32_t> ev_launches;   // scan launches between the two events of a pair
     size_t ev_used = 0;
+    // deferred selects: a step is ONE launch and the launches follow one another without a gap, which an
+    // event pair around a single launch would open (the dispatch can no longer be prepared under the
+    // previous kernel: + 2 us on a 237 us scan); the pairs therefore span runs of consecutive launches
+    uint32_t span_count = 0, span_len = 0;
+    hipEvent_t span_close = nullptr;
+    hipStream_t span_stream = nullptr;
 };
 
 namespace {
@@ -317,9 +324,12 @@ trag_status ensure_scratch_set(trag_store* s, Scratch& sc, void*& zero_block, ui
     return TRAG_OK;
 }
 
+hipError_t span_timer_close(trag_store* s);
+
 // A deferred select that is still pending: launched now, alone, on the stream its scan ran on.
 trag_status flush_pending(trag_store* s) {
     if (!s->has_pend) return TRAG_OK;
+    HIP_TRY(span_timer_close(s));   // (a run of timed launches ends where something else enters the stream)
     const PrevSelect& p = s->pend;
     s->has_pend = false;
     Scratch sc{};
@@ -563,9 +573,48 @@ hipError_t scan_timer_begin(trag_store* s, hipStream_t st, hipEvent_t* closing) 
         s->ev_pool.emplace_back(a0, a1);
     }
     const auto& pair = s->ev_pool[s->ev_used];
+    if (s->ev_launches.size() < s->ev_pool.size()) s->ev_launches.resize(s->ev_pool.size(), 1u);
+    s->ev_launches[s->ev_used] = 1u;
     s->ev_used += 1;
     *closing = pair.second;
     return hipEventRecord(pair.first, st);
+}
+
+// The same for the launches of a handle with deferred selects: one pair around every run of
+// max(profile_every, 4) consecutive launches (each launch is timed, as part of its run).
+hipError_t span_timer_close(trag_store* s) {
+    if (!s->span_close) return hipSuccess;
+    const hipError_t e = hipEventRecord(s->span_close, s->span_stream);
+    s->ev_launches[s->ev_used - 1] = s->span_count;
+    s->span_close = nullptr;
+    s->span_count = 0;
+    return e;
+}
+hipError_t span_timer_before_launch(trag_store* s, hipStream_t st) {
+    if (!s->profiling) return hipSuccess;
+    if (s->span_close && s->span_stream != st) {
+        const hipError_t e = span_timer_close(s);
+        if (e != hipSuccess) return e;
+    }
+    if (!s->span_close) {
+        const uint32_t every = s->profile_every;
+        s->profile_every = 1;
+        s->profile_seen = 0;
+        hipEvent_t closing = nullptr;
+        const hipError_t e = scan_timer_begin(s, st, &closing);
+        s->profile_every = every;
+        if (e != hipSuccess || !closing) return e;
+        s->span_close = closing;
+        s->span_stream = st;
+        s->span_count = 0;
+        s->span_len = std::max<uint32_t>(every, 4u);
+    }
+    return hipSuccess;
+}
+hipError_t span_timer_after_launch(trag_store* s) {
+    if (!s->span_close) return hipSuccess;
+    if (++s->span_count >= s->span_len) return span_timer_close(s);
+    return hipSuccess;
 }
 
 // Orders work about to be enqueued on `st` behind whatever the handle enqueued last, if that
@@ -825,7 +874,7 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     for (uint32_t b = 0; b < n_queries; ++b) {
         const float* q = d_queries + (size_t)b * s->cfg.dim;
         hipEvent_t e1 = nullptr;
-        HIP_TRY(scan_timer_begin(s, st, &e1));
+        if (!(pipe && s->deferred)) HIP_TRY(scan_timer_begin(s, st, &e1));   // (deferred launches are timed in runs)
         uint32_t n_waves = 0;
         const uint32_t group = multi_ok ? std::min<uint32_t>(multi_max, n_queries - b) : 1u;
         if (group >= 2) {
@@ -862,8 +911,9 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             }
             s->last_ctl = sc.ctl;
             HIP_TRY(next_scan_epoch(s, sc, true, st));
+            HIP_TRY(span_timer_before_launch(s, st));
             HIP_TRY(launch_scan_exact(q, a, sc, need, k_eff, s->d_vmax_sq, &n_waves, st, s->has_pend ? &s->pend : nullptr));
-            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(span_timer_after_launch(s));
             s->one_wg_queries += 1;
             PrevSelect& p = s->pend;
             p.q = q;
@@ -1733,6 +1783,10 @@ trag_status trag_store_stream_probe(trag_store* s, uint32_t repeats, double* gb_
 trag_status trag_store_set_profiling(trag_store* s, int enabled) {
     if (!s) return fail(TRAG_INVALID_ARG, "null store");
     std::lock_guard<std::mutex> lk(s->mu);
+    {
+        DeviceGuard guard(s->device);
+        HIP_TRY(span_timer_close(s));
+    }
     s->profiling = enabled != 0;
     s->profile_every = enabled > 1 ? (uint32_t)enabled : 1u;
     s->profile_seen = 0;
@@ -1744,15 +1798,18 @@ trag_status trag_store_scan_time(trag_store* s, double* total_ms, uint32_t* laun
     if (!s || !total_ms || !launches) return fail(TRAG_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     DeviceGuard guard(s->device);
+    HIP_TRY(span_timer_close(s));
     double sum = 0.0;
+    uint32_t n = 0;
     for (size_t i = 0; i < s->ev_used; ++i) {
         HIP_TRY(hipEventSynchronize(s->ev_pool[i].second));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_pool[i].first, s->ev_pool[i].second));
         sum += ms;
+        n += i < s->ev_launches.size() ? s->ev_launches[i] : 1u;
     }
     *total_ms = sum;
-    *launches = (uint32_t)s->ev_used;
+    *launches = n;
     s->ev_used = 0;
     return TRAG_OK;
 }
