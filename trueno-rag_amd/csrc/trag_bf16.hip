@@ -429,9 +429,11 @@ gemm_bf16_kernel(const float* __restrict__ corpus, const uint16_t* __restrict__ 
         // from LDS; a workgroup barrier closes every phase, and the waves NW / 2 .. NW - 1 run one phase behind
         // the others. What prompted it (stamps, -DBF_STAMP, 1 M x 768 x 256 queries): left to themselves the two
         // run the same phases at the same times -- both wait for LDS, then both want the matrix pipe, which the
-        // older one gets: its 32 MFMAs take 1770 cycles of a k-step, the younger one finishes at 2800, and the
-        // older one waits for it at the barrier (14 000 of a workgroup's 38 000 cycles). Bit-identical results,
-        // but SLOWER: 491 us against 449 for the full pass, 50 000 cycles a workgroup. MFMAs are issued
+        // older one gets: its 32 MFMAs take 1770 s_memtime ticks of a k-step (a tick is about three quarters of a
+        // shader cycle under this load; the MFMAs of both waves need 1540), the younger one finishes at 2800,
+        // and the older one waits for it at the barrier (14 000 of a workgroup's 38 000 ticks; the 1 200 - 2 200
+        // ahead of the k-loop are not where the time is). Bit-identical results,
+        // but SLOWER: 491 us against 449 for the full pass, 50 000 ticks a workgroup. MFMAs are issued
         // asynchronously, so a phase barrier does not mark the end of the multiplying, and a wave's next
         // fragment reads wait for its own MFMAs in flight to release the registers; four barriers a k-step
         // cost more than the alternation gains. (LDS is not the limit either: SQ_LDS_IDX_ACTIVE 17 % of the
