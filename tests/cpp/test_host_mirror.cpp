@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "trueno_rag.hpp"
 
 using namespace trueno_rag;
@@ -209,6 +211,52 @@ int main() {
         s.remove(c.id);
         EXPECT(s.len() == 1 && t.len() == 3 && t.search({0.0f, 1.0f}, 1)[0].second == 1.0f);
         EXPECT(s.search({0.0f, 1.0f}, 5).size() == 1);
+    }
+    {   // not in the reference: device-resident queries with deferred selects (trag_store_search_device on the
+        // handle, mode 2): six queries enqueued back to back, one fence, the host entry's answers
+        const size_t d = 64, n = 5000, k = 7, nq = 6;
+        VectorStore s = VectorStore::with_dimension(d);
+        std::vector<Chunk> cs;
+        uint32_t x = 12345u;
+        auto rnd = [&]() { x = x * 1664525u + 1013904223u; return (float)((x >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+        for (size_t i = 0; i < n; ++i) {
+            std::vector<float> v(d);
+            for (auto& e : v) e = rnd();
+            cs.push_back(chunk_with("c" + std::to_string(i), v));
+        }
+        s.insert_batch(cs);
+        std::vector<float> q(nq * d);
+        for (auto& e : q) e = rnd();
+        float* dq = nullptr; uint32_t* drows = nullptr; float* dscores = nullptr; uint32_t* dn = nullptr; uint32_t* dst = nullptr;
+        EXPECT(hipMalloc((void**)&dq, q.size() * 4) == hipSuccess && hipMalloc((void**)&drows, nq * k * 4) == hipSuccess &&
+               hipMalloc((void**)&dscores, nq * k * 4) == hipSuccess && hipMalloc((void**)&dn, nq * 4) == hipSuccess &&
+               hipMalloc((void**)&dst, nq * 4) == hipSuccess);
+        EXPECT(hipMemcpy(dq, q.data(), q.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
+        EXPECT(hipMemset(drows, 0xFF, nq * k * 4) == hipSuccess && hipMemset(dst, 0xFF, nq * 4) == hipSuccess);
+        s.set_pipelined(2);
+        for (size_t b = 0; b < nq; ++b)
+            EXPECT(trag_store_search_device(s.handle(), dq + b * d, 1, (uint32_t)d, (uint32_t)k, drows + b * k, dscores + b * k,
+                                            dn + b, dst + b, nullptr) == TRAG_OK);
+        std::vector<uint32_t> early(k);
+        EXPECT(hipDeviceSynchronize() == hipSuccess);
+        EXPECT(hipMemcpy(early.data(), drows + (nq - 1) * k, k * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        EXPECT(early[0] == 0xFFFFFFFFu);                    // the last query's select has not even been launched
+        s.fence(nullptr);
+        EXPECT(hipDeviceSynchronize() == hipSuccess);
+        std::vector<uint32_t> rows(nq * k), cnt(nq), st(nq);
+        std::vector<float> scores(nq * k);
+        EXPECT(hipMemcpy(rows.data(), drows, rows.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        EXPECT(hipMemcpy(scores.data(), dscores, scores.size() * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        EXPECT(hipMemcpy(cnt.data(), dn, nq * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        EXPECT(hipMemcpy(st.data(), dst, nq * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        s.set_pipelined(0);
+        for (size_t b = 0; b < nq; ++b) {
+            auto want = s.search(std::vector<float>(q.begin() + b * d, q.begin() + (b + 1) * d), k);
+            EXPECT(st[b] == 0 && cnt[b] == k && want.size() == k);
+            for (size_t i = 0; i < k && i < want.size(); ++i)
+                EXPECT(cs[rows[b * k + i]].id == want[i].first && scores[b * k + i] == want[i].second);
+        }
+        (void)hipFree(dq); (void)hipFree(drows); (void)hipFree(dscores); (void)hipFree(dn); (void)hipFree(dst);
     }
     {   // BM25: re-adding an id replaces its document; any k
         BM25Index ix;

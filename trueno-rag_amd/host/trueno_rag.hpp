@@ -204,6 +204,12 @@ class VectorStore {
     // prefiltering passes read instead of the f32 rows; results stay the exact f32 results.
     void set_bf16_mirror(bool enabled) { check(trag_store_set_bf16_mirror(h_, enabled ? 1 : 0)); }
     bool has_bf16_mirror() const { return trag_store_has_bf16_mirror(h_) != 0; }
+    // Not in the reference: callers whose queries and results live in device memory use trag_store_search_device on
+    // handle(); these two go with it. Mode 2 defers the select of a single query into the launch of the next
+    // query's scan, mode 1 runs it on a side stream, 0 switches both off; results (and, in mode 2, even the
+    // launch of the last query's select) are behind fence(stream).
+    void set_pipelined(int mode) { check(trag_store_set_pipelined(h_, mode)); }
+    void fence(void* hip_stream = nullptr) const { check(trag_store_fence(h_, hip_stream)); }
     trag_store* handle() const { return h_; }
 
   private:
