@@ -203,6 +203,20 @@ impl GpuVectorStore {
         let rc = unsafe { trag_store_set_bf16_mirror(self.h, enabled as i32) };
         if rc != 0 { Err(err(rc, 0, 0)) } else { Ok(()) }
     }
+    /// Not in the reference: for callers of the device entry (queries and results in device memory, the
+    /// raw handle from `handle()`). Mode 2 defers the select of a single query into the launch of the
+    /// next query's scan, mode 1 runs it on a side stream of the handle, 0 switches both off.
+    pub fn set_pipelined(&mut self, mode: i32) -> Result<()> {
+        let rc = unsafe { trag_store_set_pipelined(self.h, mode) };
+        if rc != 0 { Err(err(rc, 0, 0)) } else { Ok(()) }
+    }
+    /// Results of pipelined device-entry searches may be read on `hip_stream` only behind this (in mode 2
+    /// the last query's select is not even launched before it).
+    pub fn fence(&self, hip_stream: *mut c_void) -> Result<()> {
+        let rc = unsafe { trag_store_fence(self.h, hip_stream) };
+        if rc != 0 { Err(err(rc, 0, 0)) } else { Ok(()) }
+    }
+    pub fn handle(&self) -> *mut TragStore { self.h }
 }
 impl Drop for GpuVectorStore { fn drop(&mut self) { unsafe { trag_store_destroy(self.h) } } }
 
