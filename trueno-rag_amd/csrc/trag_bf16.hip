@@ -39,6 +39,9 @@
 #ifndef BF_PINGPONG
 #define BF_PINGPONG 0
 #endif
+#ifndef BF16_THIN_SAMPLE
+#define BF16_THIN_SAMPLE 1
+#endif
 
 namespace trag {
 
@@ -885,12 +888,13 @@ static uint32_t bf16_tile_rows(uint32_t n_queries) {
     return v == 2 ? 128 : 256;
 }
 
+// thin (sample pass of the 256-query tile only): 256 queries x 64 rows per workgroup -- see bf16_scan_metric
 template <int METRIC, int MODE, bool MIR>
 static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
-                             const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st) {
+                             const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st, bool thin = false) {
     const int variant = bf16_variant(n_queries);
     const uint32_t BM = variant == 0 ? 32 : (variant == 1 ? 64 : (variant == 2 ? 128 : 256));
-    const uint32_t BN = bf16_tile_rows(n_queries);
+    const uint32_t BN = thin ? 64u : bf16_tile_rows(n_queries);
     const uint32_t q_tiles = (n_queries + BM - 1) / BM;
     const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
     const uint32_t pass_tiles = (n_row_tiles + tile_step - 1) / tile_step;
@@ -900,7 +904,9 @@ static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16
                        st, a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows, \
                        a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys, \
                        need, s.dyn_lvl, s.dyn_lad, s.dyn_cnt)
-    if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
+    if (thin) {
+        if constexpr (MODE == 0) TRAG_LAUNCH_BF16(1, 8, 1);   // 256 queries x 64 rows, eight waves of 32 queries
+    } else if (variant == 0) TRAG_LAUNCH_BF16(1, 1, 4);       // 32 queries x 256 rows
     else if (variant == 1) TRAG_LAUNCH_BF16(2, 1, 4);  // 64 x 256
     else if (variant == 2) TRAG_LAUNCH_BF16(2, 2, 2);  // 128 x 128
     else if (MIR && !getenv("TRAG_BF16_NODMA")) {      // 256 x 256 from the mirror: direct-to-LDS staging
@@ -921,10 +927,18 @@ template <int METRIC, bool MIR>
 static void bf16_scan_metric(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror,
                              const float* d_norm2, const Bf16Scratch& s, uint32_t need, hipStream_t st) {
     const uint32_t padded = (n_queries + 255u) / 256u * 256u;
-    const uint32_t step = bf16_sample_step(a.n_rows, need, a.dim);
-    launch_gemm_bf16<METRIC, 0, MIR>(n_queries, a, d_mirror, d_norm2, s, step, need, st);
+    uint32_t step = bf16_sample_step(a.n_rows, need, a.dim);
+    // The sample pass of the 256-query tile costs one workgroup-tile's time whatever it samples (every 16th tile of a
+    // million rows is one round of workgroups: 53 us, 7 % of the step). With the thresholds tightening during the
+    // full pass a thinner sample does as well: the same number of workgroups, each over 64 rows instead of 256
+    // (1 M x 768 x 256 queries: sample 51 -> 26 us from f32 rows, 37 -> 21 from the mirror, full pass + 5 us for the
+    // longer lists, step 0.765 -> 0.744 / 0.536 -> 0.523 ms; two to four k-steps of loads in flight in the thin
+    // kernel change nothing: 26 us is its launch, twelve barrier pairs and the epilogue).
+    const bool thin = BF16_THIN_SAMPLE && bf16_variant(n_queries) == 3 && a.n_rows >= 262144u;
+    if (thin) step *= 4u;
+    launch_gemm_bf16<METRIC, 0, MIR>(n_queries, a, d_mirror, d_norm2, s, step, need, st, thin);
     // 64-row tiles the sample pass wrote maxima for (its last 128/256-row tile may be partial)
-    const uint32_t BN = bf16_tile_rows(n_queries);
+    const uint32_t BN = thin ? 64u : bf16_tile_rows(n_queries);
     const uint32_t n_row_tiles = (a.n_rows + BN - 1) / BN;
     const uint32_t pass_tiles = (n_row_tiles + step - 1) / step;
     const uint32_t n_tile64 = pass_tiles * (BN / 32);  // maxima per 32 rows; every sampled workgroup writes all of its own
