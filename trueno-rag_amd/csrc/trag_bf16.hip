@@ -861,11 +861,15 @@ double bf16_step_by_list(uint32_t need, uint32_t dim) {
     return std::max(fixed, tight);
 }
 
-// At most every 16th tile is sampled: what a sparser sample saves, the longer lists give back (1 M x 768,
-// 256 queries, ms per step from f32 rows / from the mirror: every 8th tile at most 0.86 / 0.62, 16th
-// 0.82 / 0.61, 32nd 0.81 / 0.61, 64th 0.81 / 0.61).
+// At most every 128th tile is sampled. On a million rows the cap does not matter (1 M x 768, 256 queries, ms per
+// step from f32 rows / from the mirror: every 8th tile at most 0.86 / 0.62, 16th 0.82 / 0.61, 32nd 0.81 / 0.61,
+// 64th 0.81 / 0.61: there the sample is one round of workgroups whatever its step); on a long corpus the sample
+// is bytes -- every 16th tile of 10 M x 384 is a sixteenth of the pass again -- and with the thresholds
+// tightening during the full pass a sparse one does as well: 10 M x 384, ms per step with a cap of 16 / 64 / 128,
+// 8 queries 2.377 / 2.247 / 2.229 (one query: 2.217), 32 queries 2.398 / 2.259 / 2.244, 128 queries 2.779 / 2.605 /
+// 2.586, 32 queries from the mirror 1.258 / 1.177 / 1.168.
 #ifndef BF16_MAX_STEP
-#define BF16_MAX_STEP 16
+#define BF16_MAX_STEP 128
 #endif
 uint32_t bf16_sample_step(uint64_t n_rows, uint32_t need, uint32_t dim) {
     const uint64_t n_tile64 = (n_rows + 63) / 64;
