@@ -671,15 +671,31 @@ def test_bf16_auto_and_limits(trag, oracle):
     corpus = store.read_rows(0, n)
     Q = oracle.synth_rows(78, 0, 12, d)
     rows, scores, cnt = store.search_batch_rows(Q, 10)
-    assert store.last_stats()["mode_used"] == BF16          # AUTO: from 4 queries up, large corpus
+    assert store.last_stats()["mode_used"] == BF16          # AUTO: more queries than one multi-query pass takes
     for b in range(12):
         er, es = oracle.search(corpus, Q[b], 10, 0)
         assert_same_ranking(rows[b], scores[b], er, es, f"auto bf16 {b}")
+    # 2..8 queries: the multi-query exact pass or the prefilter, whichever is cheaper for the corpus' size --
+    # on 70 k rows (a 30 us scan) the prefilter's 40 us of small launches cost more than seven extra queries
     r4, s4, _ = store.search_batch_rows(Q[:4], 10)
-    assert store.last_stats()["mode_used"] == BF16
+    assert store.last_stats()["mode_used"] == EXACT
     assert np.array_equal(r4, rows[:4]) and s4.tobytes() == scores[:4].tobytes()
-    store.search_batch_rows(Q[:3], 10)
-    assert store.last_stats()["mode_used"] == EXACT         # 2..3 queries: one exact multi-query pass
+    store.search_batch_rows(Q[:8], 10)
+    assert store.last_stats()["mode_used"] == EXACT
+    # ... on 1.5 M x 192 (a 190 us scan) four queries go to the prefilter, two stay with the multi-query pass
+    big = make_store(trag, 192, 0, 0, reserve=1_500_000)
+    big.fill_synthetic(1_500_000, 79)
+    cb = big.read_rows(0, 1_500_000)
+    Qb = oracle.synth_rows(80, 0, 4, 192)
+    rb, sb, _ = big.search_batch_rows(Qb, 10)
+    assert big.last_stats()["mode_used"] == BF16
+    for b in range(4):
+        er, es = oracle.search(cb, Qb[b], 10, 0)
+        assert_same_ranking(rb[b], sb[b], er, es, f"auto bf16, four queries on a long corpus {b}")
+    r2, s2, _ = big.search_batch_rows(Qb[:2], 10)
+    assert big.last_stats()["mode_used"] == EXACT
+    assert np.array_equal(r2, rb[:2]) and s2.tobytes() == sb[:2].tobytes()
+    big.close()
     store.search_batch_rows(Q, 300)
     assert store.last_stats()["mode_used"] == MFMA          # k too large for the candidate lists
     # clustered scores: thousands of rows within 2 eps of the k-th best overflow the lists -> exact repeat

@@ -517,6 +517,17 @@ bool use_bf16_path(const trag_store* s, uint32_t mode, uint32_t nq, uint32_t k) 
     if (mode == TRAG_SCAN_MIRROR) return s->d_mirror != nullptr && nq >= 2;
     if (mode != TRAG_SCAN_AUTO || s->bf16_off) return false;
     if (bf16_list_estimate(s->n_rows, k, s->cfg.dim) > 2048.0) return false;
+    // Up to 8 queries the alternative is the multi-query exact pass, which costs one scan plus 12 / 21 / 29 / ... / 71 %
+    // for 2 / 3 / 4 / ... / 8 queries; the prefilter costs one pass over the rows (or over the mirror: half a scan) plus
+    // some 40 us of small launches whatever the batch. Measured at d = 384 (ms per step, multi-query / prefilter): 1 M rows
+    // 2 queries 0.266 / 0.275, 3: 0.286 / 0.278, 8: 0.405 / 0.280; 250 k rows 4: 0.089 / 0.107, 8: 0.125 / 0.109; 100 k
+    // rows 8: 0.073 / 0.076; 10 M rows 2: 2.49 / 2.22.
+    const uint32_t multi_max = multi_group_limit(s->cfg.dim);
+    if (nq >= 2 && nq <= 8 && nq <= multi_max) {
+        static const double extra[9] = {0.0, 0.0, 0.12, 0.21, 0.29, 0.40, 0.50, 0.61, 0.71};
+        const double scan_s = (double)s->n_rows * s->cfg.dim * 4.0 / 6.5e12 + 12e-6;
+        return scan_s * (extra[nq] + (s->d_mirror ? 0.5 : 0.0)) > 40e-6;
+    }
     return nq >= (s->d_mirror ? 2u : 4u);
 }
 
