@@ -66,20 +66,25 @@ def test_shard_group_one_rank_runs_rccl(trag, oracle, overlap):
     store.close()
 
 
+@pytest.mark.parametrize("mirror", [False, True])
 @pytest.mark.parametrize("metric", [0, 1])
-def test_overlap_mode_single_queries_exchange_one_call_late(trag, oracle, metric):
+def test_overlap_mode_single_queries_exchange_one_call_late(trag, oracle, metric, mirror):
     """Overlap mode, one query per call: the local store defers each select into its next scan's launch,
     and the group enqueues the exchange of call i when call i + 1 has been enqueued (or at the fence).
     150 calls back to back, nothing synchronised (more than two laps of the 64-entry result ring, several
     of its periodic waits), k changing from call to call, a 5-query call and a host-entry call in the
     middle (both settle what is pending first), a second stream near the end: after one fence every
-    call's output holds the oracle's global rows and score bits."""
+    call's output holds the oracle's global rows and score bits. (The Euclidean store is short: its plan is the
+    multi-level select, whose stages the store runs on its own side stream -- nothing is deferred, and the
+    exchange must wait for that stream; the same with a bf16 mirror, whose scan's last stages run there.)"""
     import torch
     from trueno_rag_amd.sharded import ShardGroup
     n, d, N = 120_000, 64, 150
     store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, metric=trag.DistanceMetric(metric), device=0,
                                                     reserve_rows=n))
     store.fill_synthetic(n, 41)
+    if mirror:
+        store.set_bf16_mirror(True)
     corpus = store.read_rows(0, n)
     Q = oracle.synth_rows(42, 0, N, d)
     dq = torch.from_numpy(Q).cuda()

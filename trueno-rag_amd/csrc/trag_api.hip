@@ -735,12 +735,15 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
     // Pipelined form (device entry of a handle that asked for it, one exact-order query, the
     // one-workgroup select): every other route runs on `st` alone, behind whatever the pipeline still
     // has on the side stream.
-    const bool pipe_any = may_pipeline && ((s->pipelined && s->side) || s->deferred) && n_queries == 1 && !full_select &&
-                          !(k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP);
+    const bool pipe_base = may_pipeline && ((s->pipelined && s->side) || s->deferred) && n_queries == 1 &&
+                           !(k_eff > CAND_CAP - STREAM_SLACK && live > CAND_CAP);
+    const bool pipe_any = pipe_base && !full_select;
     const bool pipe = pipe_any && mode == TRAG_SCAN_EXACT;
-    // (the mirror scan's three small stages always go to the side stream: they are launches of their own)
+    // (the mirror scan's three small stages always go to the side stream: they are launches of their own;
+    // so do the stages of the multi-level select, the plan of Euclidean stores too short for sparse key stores)
     const bool pipe_mirror = pipe_any && mode == TRAG_SCAN_MIRROR && s->side && s->d_mirror;
-    if (!pipe && !pipe_mirror && (s->pipe_used[0] || s->pipe_used[1] || s->has_pend)) {
+    const bool pipe_full = pipe_base && full_select && mode == TRAG_SCAN_EXACT && s->side;
+    if (!pipe && !pipe_mirror && !pipe_full && (s->pipe_used[0] || s->pipe_used[1] || s->has_pend)) {
         ts = drain_pipeline(s, st);
         if (ts != TRAG_OK) return ts;
     }
@@ -966,6 +969,31 @@ trag_status enqueue_search(trag_store* s, const float* d_queries, uint32_t n_que
             s->one_wg_queries += 1;
             HIP_TRY(launch_select_final(q, a, sc, false, live, need, k_eff, n_waves, o_rows, o_scores, d_out_n + b,
                                         o_status, s->side));
+            HIP_TRY(hipEventRecord(s->sel_done[x], s->side));
+            s->pipe_used[x] = true;
+            continue;
+        }
+        if (pipe_full) {
+            // exact scan on the caller's stream; radix levels, compaction, ordering and the clearing of the
+            // accumulators on the side stream beside the next query's scan
+            const uint32_t x = s->pipe_next;
+            s->pipe_next ^= 1u;
+            Scratch& sc = x ? s->scratch2 : s->scratch;
+            if (s->has_pend) {
+                ts = s->pend_stream == st ? flush_pending(s) : drain_pipeline(s, st);
+                if (ts != TRAG_OK) return ts;
+            }
+            if (s->pipe_used[x]) HIP_TRY(hipStreamWaitEvent(st, s->sel_done[x], 0));
+            s->last_ctl = sc.ctl;
+            HIP_TRY(next_scan_epoch(s, sc, false, st));
+            HIP_TRY(launch_scan_exact(q, a, sc, need, k_eff, s->d_vmax_sq, &n_waves, st));
+            if (e1) HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(hipEventRecord(s->scan_done[x], st));
+            HIP_TRY(hipStreamWaitEvent(s->side, s->scan_done[x], 0));
+            HIP_TRY(launch_select(a, sc, s->side));
+            HIP_TRY(launch_final(q, a, sc, false, live, o_rows, o_scores, d_out_n + b, o_status, s->side));
+            HIP_TRY(hipMemsetAsync(sc.hist, 0, s->zero_bytes - 256, s->side));
+            HIP_TRY(launch_reset_ctl(sc, s->side));
             HIP_TRY(hipEventRecord(s->sel_done[x], s->side));
             s->pipe_used[x] = true;
             continue;
@@ -1438,6 +1466,14 @@ bool search_one_concurrent(trag_store* s, const float* query, uint32_t dim, uint
 bool trag::store_select_pending(trag_store* s) {
     std::lock_guard<std::mutex> lk(s->mu);
     return s->has_pend;
+}
+
+trag_status trag::store_wait_side(trag_store* s, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    DeviceGuard guard(s->device);
+    for (int x = 0; x < 2; ++x)
+        if (s->pipe_used[x]) HIP_TRY(hipStreamWaitEvent(st, s->sel_done[x], 0));
+    return TRAG_OK;
 }
 
 extern "C" {

@@ -174,6 +174,9 @@ struct PrevSelect {
 // Whether the handle holds a deferred select that no launch carries yet (trag_store_set_pipelined(s, 2):
 // the results of the last single query do not exist before the next scan's launch or a fence).
 bool store_select_pending(trag_store* s);
+// Makes `st` wait for the stages a pipelined handle has on its side stream (the mirror scan's, the multi-level
+// select's) without launching a deferred select that is still pending (trag_store_fence does both).
+trag_status store_wait_side(trag_store* s, hipStream_t st);
 
 // ---- kernel launchers (trag_kernels.hip) ----
 // the scans report the number of waves of their grid (tile t is scanned by wave t % n_waves)

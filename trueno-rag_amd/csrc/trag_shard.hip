@@ -417,6 +417,12 @@ trag_status trag_shard_search_device(trag_shard_group* g, trag_store* local, uin
         if (g->pend.on || !deferred_now) {
             SH_TRY(hipEventRecord(g->ev_scan, st));
             SH_TRY(hipStreamWaitEvent(g->side, g->ev_scan, 0));
+            // (a route whose last stages the store runs on its own side stream -- the mirror scan's, the
+            // multi-level select's -- has its results there, not on `st`)
+            if (!deferred_now && local_ts == TRAG_OK) {
+                ts = store_wait_side(local, g->side);
+                if (ts != TRAG_OK) return ts;
+            }
         }
         if (g->pend.on) {
             const trag_shard_group::PendingExchange P = g->pend;
