@@ -178,7 +178,7 @@ trag_status trag_store_search_device(trag_store *s, const float *d_queries, uint
  * be read on a stream only after trag_store_fence on it, and the query and the output buffers must stay
  * valid until then. On a store with the bf16 mirror, single queries take the scan of the mirror and the three
  * small stages behind it (prune, exact scores, ordering) go to the side stream in either mode (1 M x 384:
- * 0.136 ms a query against 0.154). Host-pointer entries are unaffected (they wait for their own results). Costs a second scratch
+ * 0.136 ms a query against 0.154); so do the stages of the multi-level select where that is the handle's plan. Host-pointer entries are unaffected (they wait for their own results). Costs a second scratch
  * set (8 bytes per row instead of 4). No counterpart in the reference. */
 trag_status trag_store_set_pipelined(trag_store *s, int enabled);
 /* Makes hip_stream wait for every select the handle still owes: a pending one (mode 2) is launched
