@@ -897,18 +897,6 @@ template <int METRIC, int MODE, bool MIR>
 static void launch_gemm_bf16(uint32_t n_queries, const ScanArgs& a, const uint16_t* d_mirror, const float* d_norm2,
                              const Bf16Scratch& s, uint32_t tile_step, uint32_t need, hipStream_t st, bool thin = false) {
     const int variant = bf16_variant(n_queries);
-    static const bool exp128 = getenv("TRAG_BF16_DMA128") != nullptr;   // (experiment)
-    if (exp128 && MODE == 1 && MIR && variant == 3 && !thin) {
-        if constexpr (MIR && MODE == 1) {
-            const uint32_t q_tiles = (n_queries + 127) / 128, n_row_tiles = (a.n_rows + 127) / 128;
-            const uint32_t grid = ((n_row_tiles + 7) / 8) * q_tiles * 8;
-            hipLaunchKernelGGL((gemm_bf16_kernel<METRIC, 2, 2, 2, MODE, true, true>), dim3(grid), dim3(256), 0, st,
-                               a.corpus, d_mirror, reinterpret_cast<const __bf16*>(s.qb), d_norm2, a.dead, a.n_rows,
-                               a.dim, n_queries, q_tiles, tile_step, s.ctls, s.thr, s.tmax, s.tmax_stride, s.cand, s.ckeys,
-                               need, s.dyn_lvl, s.dyn_lad, s.dyn_cnt);
-        }
-        return;
-    }
     const uint32_t BM = variant == 0 ? 32 : (variant == 1 ? 64 : (variant == 2 ? 128 : 256));
     const uint32_t BN = thin ? 64u : bf16_tile_rows(n_queries);
     const uint32_t q_tiles = (n_queries + BM - 1) / BM;
