@@ -135,6 +135,42 @@ def test_overlap_mode_single_queries_exchange_one_call_late(trag, oracle, metric
     store.close()
 
 
+@pytest.mark.parametrize("pipe_mode", [1, 2])
+def test_group_without_overlap_on_a_store_its_caller_pipelined(trag, oracle, pipe_mode):
+    """A group created without overlap enqueues the exchange on the caller's stream right behind the local
+    search. If the CALLER has put the local store into a pipelined mode, that search's select is on the
+    store's side stream or still pending: the group fences the store first. Six single-query calls and a
+    batch of three, one stream, one synchronisation."""
+    import torch
+    from trueno_rag_amd.sharded import ShardGroup
+    n, d, k, row0 = 90_000, 64, 10, 1_000_000
+    store = trag.VectorStore(trag.VectorStoreConfig(dimension=d, device=0, reserve_rows=n))
+    store.fill_synthetic(n, 51)
+    store.set_pipelined(pipe_mode)
+    corpus = store.read_rows(0, n)
+    Q = oracle.synth_rows(52, 0, 9, d)
+    dq = torch.from_numpy(Q).cuda()
+    g = ShardGroup(0, 1, 0, k_max=k, max_queries=8, overlap=False)
+    rows = torch.full((9, k), -1, dtype=torch.int32, device="cuda")
+    scores = torch.zeros((9, k), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(9, dtype=torch.int32, device="cuda")
+    status = torch.full((9,), 9, dtype=torch.int32, device="cuda")
+    user = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for i in list(range(6)) + [6]:
+        nq = 1 if i < 6 else 3
+        g.search_device(store, row0, 1, dq.data_ptr() + i * d * 4, nq, k, rows.data_ptr() + i * k * 4,
+                        scores.data_ptr() + i * k * 4, cnt.data_ptr() + i * 4, status.data_ptr() + i * 4, user.cuda_stream)
+    user.synchronize()
+    R, S, C, T = rows.cpu().numpy(), scores.cpu().numpy(), cnt.cpu().numpy(), status.cpu().numpy()
+    for i in range(9):
+        er, es = oracle.search(corpus, Q[i], k, 0)
+        assert T[i] == 0 and C[i] == k, (i, T[i], C[i])
+        assert_same_ranking(R[i].astype(np.uint32), S[i], er + row0, es, f"call {i}")
+    g.close()
+    store.close()
+
+
 def _global_oracle(oracle, corpus, dead, q, k, metric):
     d8 = np.zeros(corpus.shape[0], dtype=np.uint8)
     d8[list(dead)] = 1

@@ -458,7 +458,10 @@ trag_status trag_shard_search_device(trag_shard_group* g, trag_store* local, uin
         SH_TRY(hipEventRecord(sl.searched, st));
         SH_TRY(hipStreamWaitEvent(g->side, sl.searched, 0));
         xs = g->side;
-        // (a pipelined store has this call's select on its own side stream, not on st)
+    }
+    {
+        // (a pipelined store -- the group's own doing in overlap mode, or the caller's -- has this call's last
+        // stages on its own side stream, not on st; a no-op otherwise)
         trag_status tf = trag_store_fence(local, xs);
         if (tf != TRAG_OK) return tf;
     }
