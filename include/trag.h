@@ -313,7 +313,9 @@ typedef struct trag_shard_config {
                              launch and one event record per call (1.25 M x 384 per rank: 0.299 ms a
                              call with the exchange against 0.293 for the scan kernel alone).
                              Results are visible to a stream only after trag_shard_fence on it;
-                             output buffers must stay valid until then. */
+                             output buffers must stay valid until then. The store keeps that mode
+                             when the group is done with it: searches made on it directly afterwards
+                             need trag_store_fence, or trag_store_set_pipelined(store, 0) first. */
 } trag_shard_config;
 trag_status trag_shard_unique_id(uint8_t *id /* TRAG_SHARD_ID_BYTES */);
 trag_status trag_shard_group_create(const trag_shard_config *cfg, const uint8_t *id, trag_shard_group **out);
