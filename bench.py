@@ -96,6 +96,11 @@ def main():
         sys.exit(subprocess.call(cmd))
     if world != args.gpus and rank == 0:
         print(f"--gpus {args.gpus} but WORLD_SIZE={world}: running with {world} rank(s)", file=sys.stderr)
+    # stdout carries ONE line, the result. Whatever libraries write to file descriptor 1 on their own (RCCL prints a
+    # version banner there when NCCL_DEBUG is set in the environment) goes to stderr instead.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch.distributed as dist
     # HBM traffic of the scan kernel from the hardware counters: a short copy of this very run
     # under rocprofv3, started before this process touches the GPU
@@ -511,7 +516,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:   # the CPU leg belongs to the single-GPU line only
             result["cpu_baseline"] = cpu_baseline(store, Q, n_local, n_total, d, k, args.cpu_sample_rows,
                                                   seed, row0, metric_id)
-        print(json.dumps(result), flush=True)
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     if group is not None:
         group.close()
     if world > 1:
