@@ -66,13 +66,17 @@ typedef enum trag_scan_mode {
     TRAG_SCAN_AUTO = 0,
     TRAG_SCAN_EXACT = 1,  /* every row scored with the reference's sequential f32 order */
     TRAG_SCAN_STREAM = 2, /* reassociated streaming scan + exact re-score of candidates */
-    TRAG_SCAN_MFMA = 3,   /* query batches as Q x D^T on the matrix cores + exact re-score
-                             (dim % 32 == 0); AUTO picks it above 8 queries;
-                             2..8 queries share one exact corpus pass */
+    TRAG_SCAN_MFMA = 3,   /* query batches as Q x D^T on the f32 matrix cores + exact re-score
+                             (dim % 32 == 0); AUTO picks it above 8 queries where the bf16 pass
+                             below does not apply; 2..8 queries on a short corpus share one
+                             exact corpus pass */
     TRAG_SCAN_BF16 = 4,   /* query batches: a bf16 matrix-core pass picks, per query, every row
                              that can be in the top k (rigorous error bound), no score matrix is
-                             written, and those rows are scored exactly in f32 (dim % 64 == 0);
-                             AUTO uses it from 4 queries up on large corpora */
+                             written, and those rows are scored exactly in f32 (dim % 64 == 0,
+                             at least 65 536 rows, k <= 256). AUTO uses it above 8 queries, and
+                             from 2 queries up where the extra queries of a multi-query exact pass
+                             would cost more than this pass's small launches (2 queries from about
+                             1.4 M x 384 rows, 4 from 0.5 M, 8 from 0.2 M) */
     TRAG_SCAN_MIRROR = 5  /* needs the bf16 mirror (trag_store_set_bf16_mirror): single queries
                              scan the mirror (half the bytes), the rows that can be in the top
                              k under a rigorous bound are then scored exactly in f32; batches
